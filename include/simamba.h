@@ -1,0 +1,153 @@
+/*
+ * simamba.h -- C ABI of libsimamba_hip.so, the MI355X (gfx950) implementation of the
+ * SI-Mamba hot path: selective scan (fwd+bwd), causal depthwise conv1d (fwd+bwd) and
+ * the k-NN graph-Laplacian eigen-ordering.
+ *
+ * The reference (denix56/SI-Mamba) is pure Python; the native code on this path lives in
+ * un-vendored wheels.  Each entry point below names the reference call site whose native
+ * callee it replaces (paths relative to the reference repo):
+ *
+ *   simamba_selective_scan_fwd/bwd   selective_scan_cuda.fwd/bwd of mamba-ssm, reached from
+ *                                    models/block.py:72 (self.mixer(...)) with the mixer built
+ *                                    at models/point_mamba.py:162.
+ *   simamba_causal_conv1d_fwd/bwd    causal_conv1d_cuda.causal_conv1d_fwd/bwd of causal-conv1d,
+ *                                    same call site (inside the mixer).
+ *   simamba_knn_graph                models/point_mamba.py:620-661 and :664-715
+ *                                    (create_graph_from_centers / ..._feature_space_...).
+ *   simamba_laplacian_topk           models/point_mamba.py:717-761 and :764-814
+ *                                    (per-sample torch.linalg.eigh loop, cuSOLVER underneath).
+ *   simamba_spectral_topk            the two above fused: centres -> top-k eigenpairs + orders.
+ *   simamba_argsort_rows             the torch.sort of models/point_mamba.py:820.
+ *
+ * Conventions
+ *   - Plain pointers and sizes only.  All pointers are DEVICE pointers unless noted.
+ *   - The caller owns every buffer (incl. workspace); the library allocates nothing and keeps
+ *     no mutable global state.  Calls only enqueue work on `stream` (a hipStream_t passed as
+ *     void*); no device-wide synchronisation, no default-stream use, no hipSetDevice.
+ *   - Return 0 on success; <0 = argument error detected before any launch (SIMAMBA_E_*);
+ *     >0 = hipError_t reported by the runtime for the launch.  simamba_strerror() decodes both.
+ *   - Tensors are contiguous in the layouts stated per function.
+ *   - io_dtype: SIMAMBA_F32 or SIMAMBA_BF16 for activation-sized tensors; all state,
+ *     accumulation and parameter gradients are fp32.
+ */
+#ifndef SIMAMBA_H_
+#define SIMAMBA_H_
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SIMAMBA_ABI_VERSION 1
+
+#define SIMAMBA_F32  0
+#define SIMAMBA_BF16 1
+
+#define SIMAMBA_OK            0
+#define SIMAMBA_E_NULLPTR    -1
+#define SIMAMBA_E_SHAPE      -2
+#define SIMAMBA_E_DTYPE      -3
+#define SIMAMBA_E_DSTATE     -4   /* dstate must be in [1,16] */
+#define SIMAMBA_E_WIDTH      -5   /* conv width must be in [2,4] */
+#define SIMAMBA_E_WORKSPACE  -6
+#define SIMAMBA_E_GROUPS     -7   /* G must be in [2,128], knn < G, k <= G */
+#define SIMAMBA_E_ALIGN      -8
+
+/* timesteps per scan chunk; simamba_scan_num_chunks(L) = ceil(L / chunk) */
+#define SIMAMBA_SCAN_CHUNK 128
+
+int         simamba_abi_version(void);
+const char* simamba_strerror(int rc);           /* host string, static storage */
+int         simamba_scan_num_chunks(int seqlen);
+
+/*
+ * Selective scan forward.
+ *   u, delta, z, out : (batch, dim, seqlen)  io_dtype      z may be NULL (no gating)
+ *   A                : (dim, dstate) fp32                   (already -exp(A_log))
+ *   B, C             : (batch, dstate, seqlen) io_dtype
+ *   D, delta_bias    : (dim) fp32, may be NULL
+ *   x_ckpt           : (batch, dim, nchunks, dstate) fp32 or NULL.  State at the END of every
+ *                      chunk; required by the backward when nchunks > 1.
+ *   last_state       : (batch, dim, dstate) fp32 or NULL.
+ *   out = (scan(u, softplus?(delta + delta_bias), A, B, C) + D*u) * silu(z)
+ */
+int simamba_selective_scan_fwd(const void* u, const void* delta, const float* A,
+                               const void* B, const void* C, const float* D, const void* z,
+                               const float* delta_bias, void* out, float* x_ckpt,
+                               float* last_state, int batch, int dim, int seqlen, int dstate,
+                               int io_dtype, int delta_softplus, void* stream);
+
+/*
+ * Selective scan backward.  Inputs as forward (+ dout, x_ckpt from the forward when
+ * nchunks > 1).  du, ddelta, dz : io_dtype (dz NULL iff z NULL).
+ * dA (dim,dstate), dB, dC (batch,dstate,seqlen), dD, ddelta_bias (dim): fp32; the library
+ * zeroes them on `stream` and then accumulates (float atomics: last-bit run-to-run jitter).
+ * dD / ddelta_bias may be NULL when D / delta_bias are NULL.
+ */
+int simamba_selective_scan_bwd(const void* u, const void* delta, const float* A,
+                               const void* B, const void* C, const float* D, const void* z,
+                               const float* delta_bias, const void* dout, const float* x_ckpt,
+                               void* du, void* ddelta, float* dA, float* dB, float* dC,
+                               float* dD, void* dz, float* ddelta_bias,
+                               int batch, int dim, int seqlen, int dstate,
+                               int io_dtype, int delta_softplus, void* stream);
+
+/*
+ * Causal depthwise conv1d (+ optional SiLU).
+ *   x, out, dout, dx : (batch, dim, seqlen) io_dtype
+ *   w : (dim, width) fp32; bias : (dim) fp32 or NULL; dw, dbias fp32, zeroed then accumulated.
+ *   out[b,d,t] = act(bias[d] + sum_k w[d,k] * x[b,d,t-(width-1)+k])
+ */
+int simamba_causal_conv1d_fwd(const void* x, const float* w, const float* bias, void* out,
+                              int batch, int dim, int seqlen, int width, int silu,
+                              int io_dtype, void* stream);
+int simamba_causal_conv1d_bwd(const void* x, const float* w, const float* bias,
+                              const void* dout, void* dx, float* dw, float* dbias,
+                              int batch, int dim, int seqlen, int width, int silu,
+                              int io_dtype, void* stream);
+
+/* ---- spectral ordering ---------------------------------------------------------------- */
+#define SIMAMBA_SPEC_SYMMETRIC   0x01u  /* also write A[j,i] for every kNN edge (i,j)          */
+#define SIMAMBA_SPEC_SELF_LOOP   0x02u  /* keep the nearest neighbour (the point itself)        */
+#define SIMAMBA_SPEC_BINARY      0x04u  /* edge weight 1 instead of exp(-alpha d^2)             */
+#define SIMAMBA_SPEC_MATRIX_SYM  0x08u  /* L = I - D^-1/2 A D^-1/2, take k+1, drop the first    */
+#define SIMAMBA_SPEC_SMALLEST    0x10u  /* k smallest eigenvalues (else k largest)              */
+#define SIMAMBA_SPEC_SIGMA_MEAN  0x20u  /* weight exp(-d^2 / 2 sigma^2), sigma = mean distance
+                                           over the whole batch (reference alpha == 0 branch)  */
+
+/*
+ * k-NN graph adjacency.  points (B,G,F) fp32 -> adj (B,G,G) fp32.
+ * workspace: >= simamba_spectral_workspace_bytes(B,G) bytes (used by SIGMA_MEAN only).
+ */
+int simamba_knn_graph(const float* points, float* adj, void* workspace, size_t ws_bytes,
+                      int B, int G, int F, int knn, float alpha, unsigned flags, void* stream);
+
+/*
+ * Laplacian eigen-decomposition, one workgroup per sample (cyclic Jacobi, LDS-resident).
+ *   adj        : (B,G,G) fp32
+ *   evals      : (B,k)      evecs : (B,G,k)      order : (B,k,G) int64 (ascending argsort of
+ *                each selected eigenvector, ties by index); any of the three may be NULL.
+ *   all_evals  : (B,G) ascending, all_evecs : (B,G,G) columns = eigenvectors; may be NULL.
+ * Reproduces the reference's quirk of decomposing the LOWER TRIANGLE of I - D^-1 A.
+ * Eigenvector sign: the component of largest magnitude is made positive (LAPACK/cuSOLVER
+ * leave the sign unspecified).
+ */
+int simamba_laplacian_topk(const float* adj, float* evals, float* evecs, long long* order,
+                           float* all_evals, float* all_evecs, int B, int G, int k,
+                           unsigned flags, void* stream);
+
+size_t simamba_spectral_workspace_bytes(int B, int G);
+
+/* centres (B,G,3) -> top-k eigenpairs + orders; workspace holds the (B,G,G) adjacency. */
+int simamba_spectral_topk(const float* centers, float* evals, float* evecs, long long* order,
+                          void* workspace, size_t ws_bytes, int B, int G, int knn, float alpha,
+                          int k, unsigned flags, void* stream);
+
+/* vals (rows, n) fp32 -> idx (rows, n) int64, ascending, ties by index.  n <= 1024. */
+int simamba_argsort_rows(const float* vals, long long* idx, int rows, int n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SIMAMBA_H_ */

@@ -1,0 +1,142 @@
+"""ctypes binding of libsimamba_hip.so (C ABI: include/simamba.h).
+
+The product path has NO fallback: if the shared library is missing or a symbol
+is absent, importing an op raises.  Nothing here (or anywhere in this package)
+imports ``oracle``.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_size_t, c_uint, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsimamba_hip.so")
+
+F32, BF16 = 0, 1
+
+SPEC_SYMMETRIC = 0x01
+SPEC_SELF_LOOP = 0x02
+SPEC_BINARY = 0x04
+SPEC_MATRIX_SYM = 0x08
+SPEC_SMALLEST = 0x10
+SPEC_SIGMA_MEAN = 0x20
+
+# name -> (restype, argtypes); mirrors include/simamba.h one to one
+_P = c_void_p
+SIGNATURES = {
+    "simamba_abi_version": (c_int, []),
+    "simamba_strerror": (c_char_p, [c_int]),
+    "simamba_scan_num_chunks": (c_int, [c_int]),
+    "simamba_selective_scan_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
+                                           c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "simamba_selective_scan_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
+                                           _P, _P, _P, _P, _P, _P, _P, _P,
+                                           c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "simamba_causal_conv1d_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "simamba_causal_conv1d_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P,
+                                          c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "simamba_knn_graph": (c_int, [_P, _P, _P, c_size_t, c_int, c_int, c_int, c_int, c_float, c_uint, _P]),
+    "simamba_laplacian_topk": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_uint, _P]),
+    "simamba_spectral_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "simamba_spectral_topk": (c_int, [_P, _P, _P, _P, _P, c_size_t, c_int, c_int, c_int, c_float,
+                                      c_int, c_uint, _P]),
+    "simamba_argsort_rows": (c_int, [_P, _P, c_int, c_int, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the library once; raise (never fall back) when it is not there."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C si_mamba_amd/csrc`.  si_mamba_amd has no CPU / eager fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the ABI and this table disagree
+        fn.restype = res
+        fn.argtypes = args
+    got = lib.simamba_abi_version()
+    if got != 1:
+        raise RuntimeError(f"libsimamba_hip.so ABI version {got}, binding expects 1")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().simamba_strerror(rc).decode()
+        raise RuntimeError(f"{what} failed (rc={rc}): {msg}")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def dtype_code(dtype):
+    import torch
+    if dtype == torch.float32:
+        return F32
+    if dtype == torch.bfloat16:
+        return BF16
+    raise TypeError(f"si_mamba_amd kernels take float32 or bfloat16 activations, got {dtype}")
+
+
+def stream_ptr(device):
+    import torch
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def require_gpu(t, what):
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"{what}: tensor is on {t.device}; si_mamba_amd runs on a ROCm device only "
+            "(no CPU fallback -- the CPU restatement lives in oracle/ and is test-only)")
+
+
+# ---- optional per-kernel device timing (used by bench.py only) -----------------------------------
+# When enabled, each C-ABI launch is bracketed by two events recorded on the stream it is enqueued
+# on; nothing synchronises until `kernel_times()` is read after the timed region.
+_timing = {"on": False, "events": {}}
+
+
+def enable_kernel_timing(on=True):
+    _timing["on"] = bool(on)
+    _timing["events"] = {}
+
+
+class timed:
+    __slots__ = ("name", "dev", "ev")
+
+    def __init__(self, name, device):
+        self.name, self.dev, self.ev = name, device, None
+
+    def __enter__(self):
+        if _timing["on"]:
+            import torch
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(torch.cuda.current_stream(self.dev))
+            self.ev = (a, b)
+        return self
+
+    def __exit__(self, *exc):
+        if self.ev is not None:
+            import torch
+            self.ev[1].record(torch.cuda.current_stream(self.dev))
+            _timing["events"].setdefault(self.name, []).append(self.ev)
+        return False
+
+
+def kernel_times():
+    """name -> (launches, mean ms); call after torch.cuda.synchronize()."""
+    out = {}
+    for name, evs in _timing["events"].items():
+        ms = [a.elapsed_time(b) for a, b in evs]
+        out[name] = (len(ms), sum(ms) / max(len(ms), 1))
+    return out

@@ -1,0 +1,131 @@
+"""Host-side mirror of the reference's operator API around the mixer.
+
+  Block          reference models/block.py:17-76   (Add -> LayerNorm -> mixer, DropPath)
+  create_block   reference models/point_mamba.py:147-175
+  _init_weights  reference models/point_mamba.py:115-144
+  MixerModel     reference models/point_mamba.py:178-272
+
+Same constructor arguments, forward signatures, return values and parameter names, so a
+state_dict of the reference's ``blocks.*`` loads unchanged.  The Triton fused add+norm path
+(``fused_add_norm=True``) is never enabled by any reference config and is refused here
+(no Triton in this framework).
+"""
+from __future__ import annotations
+
+import math
+from functools import partial
+from typing import Optional
+
+import torch
+import torch.nn as nn
+from torch import Tensor
+
+from .mamba_simple import Mamba
+
+
+class DropPath(nn.Module):
+    """Per-sample stochastic depth (the timm layer the reference imports at models/block.py:13)."""
+
+    def __init__(self, drop_prob: float = 0.0, scale_by_keep: bool = True):
+        super().__init__()
+        self.drop_prob = drop_prob
+        self.scale_by_keep = scale_by_keep
+
+    def forward(self, x):
+        if self.drop_prob == 0.0 or not self.training:
+            return x
+        keep = 1.0 - self.drop_prob
+        mask = x.new_empty((x.shape[0],) + (1,) * (x.dim() - 1)).bernoulli_(keep)
+        if keep > 0.0 and self.scale_by_keep:
+            mask.div_(keep)
+        return x * mask
+
+
+class Block(nn.Module):
+    def __init__(self, dim, mixer_cls, norm_cls=nn.LayerNorm, fused_add_norm=False,
+                 residual_in_fp32=False, drop_path=0.):
+        super().__init__()
+        if fused_add_norm:
+            raise NotImplementedError("fused_add_norm (Triton) is not part of this framework; "
+                                      "no reference config enables it")
+        self.residual_in_fp32 = residual_in_fp32
+        self.fused_add_norm = False
+        self.mixer = mixer_cls(dim)
+        self.norm = norm_cls(dim)
+        self.drop_path = DropPath(drop_path) if drop_path > 0. else nn.Identity()
+
+    def forward(self, hidden_states: Tensor, residual: Optional[Tensor] = None, inference_params=None):
+        """hidden_states = Mixer(LN(residual)); returns (hidden_states, residual)."""
+        residual = (self.drop_path(hidden_states) + residual) if residual is not None else hidden_states
+        hidden_states = self.norm(residual.to(dtype=self.norm.weight.dtype))
+        if self.residual_in_fp32:
+            residual = residual.to(torch.float32)
+        hidden_states = self.mixer(hidden_states, inference_params=inference_params)
+        return hidden_states, residual
+
+    def allocate_inference_cache(self, batch_size, max_seqlen, dtype=None, **kwargs):
+        return self.mixer.allocate_inference_cache(batch_size, max_seqlen, dtype=dtype, **kwargs)
+
+
+def _init_weights(module, n_layer, initializer_range=0.02, rescale_prenorm_residual=True,
+                  n_residuals_per_layer=1):
+    if isinstance(module, nn.Linear):
+        if module.bias is not None and not getattr(module.bias, "_no_reinit", False):
+            nn.init.zeros_(module.bias)
+    elif isinstance(module, nn.Embedding):
+        nn.init.normal_(module.weight, std=initializer_range)
+    if rescale_prenorm_residual:
+        # GPT-2 style: residual-branch output projections scaled by 1/sqrt(#residual layers)
+        for name, p in module.named_parameters():
+            if name in ("out_proj.weight", "fc2.weight"):
+                nn.init.kaiming_uniform_(p, a=math.sqrt(5))
+                with torch.no_grad():
+                    p /= math.sqrt(n_residuals_per_layer * n_layer)
+
+
+def create_block(d_model, ssm_cfg=None, norm_epsilon=1e-5, rms_norm=False, residual_in_fp32=False,
+                 fused_add_norm=False, layer_idx=None, drop_path=0., device=None, dtype=None):
+    if rms_norm:
+        raise NotImplementedError("rms_norm=True needs mamba-ssm's Triton RMSNorm; every reference cfg sets False")
+    ssm_cfg = {} if ssm_cfg is None else ssm_cfg
+    factory_kwargs = {"device": device, "dtype": dtype}
+    mixer_cls = partial(Mamba, layer_idx=layer_idx, **ssm_cfg, **factory_kwargs)
+    norm_cls = partial(nn.LayerNorm, eps=norm_epsilon, **factory_kwargs)
+    block = Block(d_model, mixer_cls, norm_cls=norm_cls, fused_add_norm=fused_add_norm,
+                  residual_in_fp32=residual_in_fp32, drop_path=drop_path)
+    block.layer_idx = layer_idx
+    return block
+
+
+class MixerModel(nn.Module):
+    def __init__(self, d_model: int, n_layer: int, ssm_cfg=None, norm_epsilon: float = 1e-5,
+                 rms_norm: bool = False, initializer_cfg=None, fused_add_norm=False,
+                 residual_in_fp32=False, drop_out_in_block: float = 0., drop_path: float = 0.1,
+                 device=None, dtype=None) -> None:
+        factory_kwargs = {"device": device, "dtype": dtype}
+        super().__init__()
+        self.residual_in_fp32 = residual_in_fp32
+        self.fused_add_norm = fused_add_norm
+        self.layers = nn.ModuleList([
+            create_block(d_model, ssm_cfg=ssm_cfg, norm_epsilon=norm_epsilon, rms_norm=rms_norm,
+                         residual_in_fp32=residual_in_fp32, fused_add_norm=fused_add_norm, layer_idx=i,
+                         drop_path=drop_path, **factory_kwargs)
+            for i in range(n_layer)])
+        self.norm_f = nn.LayerNorm(d_model, eps=norm_epsilon, **factory_kwargs)
+        self.apply(partial(_init_weights, n_layer=n_layer,
+                           **(initializer_cfg if initializer_cfg is not None else {})))
+        self.drop_path = DropPath(drop_path) if drop_path > 0. else nn.Identity()
+        self.drop_out_in_block = nn.Dropout(drop_out_in_block) if drop_out_in_block > 0. else nn.Identity()
+
+    def allocate_inference_cache(self, batch_size, max_seqlen, dtype=None, **kwargs):
+        return {i: layer.allocate_inference_cache(batch_size, max_seqlen, dtype=dtype, **kwargs)
+                for i, layer in enumerate(self.layers)}
+
+    def forward(self, input_ids, pos, inference_params=None):
+        hidden_states = input_ids + pos
+        residual = None
+        for layer in self.layers:
+            hidden_states, residual = layer(hidden_states, residual, inference_params=inference_params)
+            hidden_states = self.drop_out_in_block(hidden_states)
+        residual = (hidden_states + residual) if residual is not None else hidden_states
+        return self.norm_f(residual.to(dtype=self.norm_f.weight.dtype))

@@ -1,0 +1,292 @@
+// Selective-scan backward for gfx950.  Decomposition: see scan_common.h.
+//
+// Replaces selective_scan_cuda.bwd of mamba-ssm (autograd of the call at the reference's
+// models/block.py:72).  Per (row, state n) the kernel re-runs the forward scan to get h_t, runs
+// the adjoint scan g_t = C_t dy_t + a_{t+1} g_{t+1} right-to-left over the same 16 lanes, and
+// forms all gradients in registers.  Reductions:
+//   dB, dC  (sum over channels): v_permlane32_swap/v_permlane16_swap transposing reduction over
+//           the wave's 4 channel rows -> ds_add_f32 into an LDS tile shared by the workgroup's
+//           16*R channels -> one coalesced float-atomic flush per workgroup and chunk;
+//   dA, dD, ddelta_bias (sum over time and batch): DPP row all-reduce -> one atomic per row.
+// Algorithmic HBM bytes: 7*B*D*L*s + 2*B*N*L*(s+4) + small.
+#include "scan_common.h"
+
+namespace simamba {
+
+__device__ __forceinline__ void swap32_add(float& x, float y) {
+  auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, y),
+                                            false, false);
+  x = __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
+}
+__device__ __forceinline__ void swap16_add(float& x, float y) {
+  auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, y),
+                                            false, false);
+  x = __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
+}
+
+template <typename T, int kItems>
+__global__ __launch_bounds__(kScanThreads) void scan_bwd_kernel(ScanArgs p) {
+  constexpr int LC = 16 * kItems;
+  constexpr int LDP = LC + 4;
+  constexpr int KH = kItems / 2;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sB = smem;                          // [kMaxState][LDP]
+  float* sC = sB + kMaxState * LDP;          // [kMaxState][LDP]
+  float* sAcc = sC + kMaxState * LDP;        // [2][kMaxState][LC]   dB / dC of this chunk
+  float* sG = sAcc + 2 * kMaxState * LC;     // [16*passes][kMaxState] adjoint state entering from the right
+  float* sDf = sG + kRowsPerPass * p.passes * kMaxState;  // [16*passes] delta of the next chunk's first step
+
+  const int b = blockIdx.y;
+  const int tile_base = blockIdx.x * (kRowsPerPass * p.passes);
+  const int lane16 = threadIdx.x & 15;
+  const int rowslot = threadIdx.x >> 4;
+  const int sub = rowslot & 3;               // channel row inside the wave
+  const int L = p.seqlen, D = p.dim, N = p.dstate;
+  const T* __restrict__ ug = static_cast<const T*>(p.u);
+  const T* __restrict__ dg = static_cast<const T*>(p.delta);
+  const T* __restrict__ zg = static_cast<const T*>(p.z);
+  const T* __restrict__ gg = static_cast<const T*>(p.dout);
+  T* __restrict__ dug = static_cast<T*>(p.du);
+  T* __restrict__ ddg = static_cast<T*>(p.ddelta);
+  T* __restrict__ dzg = static_cast<T*>(p.dz);
+  const bool vec = p.vec != 0;
+
+  for (int c = p.nchunks - 1; c >= 0; --c) {
+    __syncthreads();
+    stage_bc<T, LC>(static_cast<const T*>(p.B), static_cast<const T*>(p.C), sB, sC, b, N, L, c);
+    for (int i = threadIdx.x; i < 2 * kMaxState * LC; i += kScanThreads) sAcc[i] = 0.f;
+    __syncthreads();
+    const bool last_chunk = (c == p.nchunks - 1);
+
+    for (int r = 0; r < p.passes; ++r) {
+      const int slot = r * kRowsPerPass + rowslot;
+      const int d = tile_base + slot;
+      const bool dvalid = d < D;
+      const int dc = dvalid ? d : D - 1;
+      const int t0 = c * LC + lane16 * kItems;
+      int nvalid = L - t0;
+      nvalid = nvalid < 0 ? 0 : (nvalid > kItems ? kItems : nvalid);
+      const size_t off = (static_cast<size_t>(b) * D + dc) * L + t0;
+
+      float u[kItems], dl[kItems], sg[kItems], zz[kItems], dy[kItems], go[kItems];
+      float ypre[kItems], dxs[kItems], dda[kItems], du[kItems];
+      load_items<T, kItems>(ug + off, nvalid, vec, u);
+      load_items<T, kItems>(dg + off, nvalid, vec, dl);
+      load_items<T, kItems>(gg + off, nvalid, vec, go);
+      if (zg) load_items<T, kItems>(zg + off, nvalid, vec, zz);
+
+      const float bias = p.delta_bias ? p.delta_bias[dc] : 0.f;
+      const float Dd = p.D ? p.D[dc] : 0.f;
+      float sumd = 0.f;
+#pragma unroll
+      for (int i = 0; i < kItems; ++i) {
+        float x = dl[i] + bias;
+        float s = 1.f;
+        if (p.softplus) {
+          s = (x > 20.f) ? 1.f : sigmoid_f(x);
+          x = softplus_f(x);
+        }
+        const bool ok = i < nvalid;
+        x = ok ? x : 0.f;
+        dl[i] = x;
+        sg[i] = s;
+        sumd += x;
+        du[i] = x * u[i];
+        go[i] = (ok && dvalid) ? go[i] : 0.f;
+        dy[i] = zg ? go[i] * zz[i] * sigmoid_f(zz[i]) : go[i];
+        ypre[i] = Dd * u[i];
+        dxs[i] = 0.f;
+        dda[i] = 0.f;
+      }
+      // delta of the step right after this lane's last one (next lane, or next chunk for lane 15)
+      const float dnext_chunk = last_chunk ? 0.f : sDf[slot];
+      const float dnext = dpp<DPP_ROW_SHL + 1>(dnext_chunk, dl[0]);
+
+      const float* __restrict__ Arow = p.A + static_cast<size_t>(dc) * N;
+      const float* __restrict__ ck =
+          (c > 0) ? p.x_ckpt + ((static_cast<size_t>(b) * D + dc) * p.nchunks + (c - 1)) * N : nullptr;
+      float dAlane = 0.f;   // lane n of the row ends up holding dA[d][n] of this chunk
+
+      for (int n = 0; n < N; ++n) {
+        const float A2 = Arow[n] * kLog2e;
+        const float* bp = sB + n * LDP + lane16 * kItems;
+        const float* cp = sC + n * LDP + lane16 * kItems;
+        float a[kItems], bw[kItems], cc[kItems], hp[kItems];
+#pragma unroll
+        for (int i = 0; i < kItems; i += 4) {
+          float4 vb = *reinterpret_cast<const float4*>(bp + i);
+          float4 vc = *reinterpret_cast<const float4*>(cp + i);
+          bw[i] = vb.x; bw[i + 1] = vb.y; bw[i + 2] = vb.z; bw[i + 3] = vb.w;
+          cc[i] = vc.x; cc[i + 1] = vc.y; cc[i + 2] = vc.z; cc[i + 3] = vc.w;
+        }
+        // ---- forward re-scan: h_t -------------------------------------------------------
+        float S = 0.f;
+#pragma unroll
+        for (int i = 0; i < kItems; ++i) {
+          a[i] = fast_exp2(dl[i] * A2);
+          S = fmaf(a[i], S, du[i] * bw[i]);
+        }
+        float P = fast_exp2(A2 * sumd);
+        row_scan_inclusive(P, S);
+        const float Pex = dpp<DPP_ROW_SHR + 1>(1.f, P);
+        const float Sex = dpp<DPP_ROW_SHR + 1>(0.f, S);
+        const float hc = ck ? ck[n] : 0.f;
+        float h = fmaf(Pex, hc, Sex);
+        float red[2 * kItems];   // [0,K): dB terms, [K,2K): dC terms
+#pragma unroll
+        for (int i = 0; i < kItems; ++i) {
+          hp[i] = h;
+          h = fmaf(a[i], h, du[i] * bw[i]);
+          ypre[i] = fmaf(cc[i], h, ypre[i]);
+          red[kItems + i] = dy[i] * h;
+          cc[i] = cc[i] * dy[i];          // c_t = C_t * dy_t, source term of the adjoint scan
+        }
+        // ---- adjoint scan, right to left: g_t = c_t + a_{t+1} g_{t+1} -------------------
+        const float anext = fast_exp2(dnext * A2);
+        float G = 0.f;
+#pragma unroll
+        for (int i = kItems - 1; i >= 0; --i) {
+          const float al = (i == kItems - 1) ? anext : a[i + 1];
+          G = fmaf(al, G, cc[i]);
+        }
+        float Q = fast_exp2(A2 * (sumd - dl[0] + dnext));
+        row_scan_inclusive_rev(Q, G);
+        const float Qex = dpp<DPP_ROW_SHL + 1>(1.f, Q);
+        const float Gex = dpp<DPP_ROW_SHL + 1>(0.f, G);
+        const float gcar = last_chunk ? 0.f : sG[slot * kMaxState + n];
+        float g = fmaf(Qex, gcar, Gex);
+        if (c > 0 && lane16 == 0) sG[slot * kMaxState + n] = fmaf(Q, gcar, G);
+        float dAacc = 0.f;
+#pragma unroll
+        for (int i = kItems - 1; i >= 0; --i) {
+          const float al = (i == kItems - 1) ? anext : a[i + 1];
+          g = fmaf(al, g, cc[i]);
+          red[i] = g * du[i];
+          dxs[i] = fmaf(g, bw[i], dxs[i]);
+          const float q = g * a[i] * hp[i];
+          dda[i] = fmaf(A2, q, dda[i]);
+          dAacc = fmaf(dl[i], q, dAacc);
+        }
+        dAacc = row_allreduce_sum(dAacc);
+        dAlane = (lane16 == n) ? dAacc : dAlane;
+        // ---- dB / dC: reduce over the wave's 4 channel rows, then into the LDS tile ------
+#pragma unroll
+        for (int i = 0; i < kItems; ++i) swap32_add(red[i], red[kItems + i]);
+#pragma unroll
+        for (int i = 0; i < KH; ++i) swap16_add(red[i], red[KH + i]);
+        // row `sub` now holds: tensor = sub>>1 (0 dB, 1 dC), items [ (sub&1)*KH, +KH )
+        float* accp = sAcc + ((sub >> 1) * kMaxState + n) * LC + lane16 * kItems + (sub & 1) * KH;
+#pragma unroll
+        for (int i = 0; i < KH; ++i) atomicAdd(accp + i, red[i]);
+      }
+
+      // ---- per-timestep gradients ---------------------------------------------------------
+      float ddl[kItems], dzv[kItems];
+      float sD = 0.f, sBias = 0.f;
+#pragma unroll
+      for (int i = 0; i < kItems; ++i) {
+        const float gd = fmaf(u[i], dxs[i], kLn2 * dda[i]) * sg[i];
+        ddl[i] = gd;
+        sBias += gd;
+        sD = fmaf(dy[i], u[i], sD);
+        du[i] = fmaf(dl[i], dxs[i], Dd * dy[i]);
+        if (zg) {
+          const float s = sigmoid_f(zz[i]);
+          dzv[i] = go[i] * ypre[i] * s * (1.f + zz[i] * (1.f - s));
+        }
+      }
+      if (dvalid) {
+        store_items<T, kItems>(dug + off, nvalid, vec, du);
+        store_items<T, kItems>(ddg + off, nvalid, vec, ddl);
+        if (zg) store_items<T, kItems>(dzg + off, nvalid, vec, dzv);
+      }
+      sD = row_allreduce_sum(sD);
+      sBias = row_allreduce_sum(sBias);
+      if (dvalid) {
+        if (lane16 < N) atomicAdd(&p.dA[static_cast<size_t>(d) * N + lane16], dAlane);
+        if (lane16 == 0 && p.dD) atomicAdd(&p.dD[d], sD);
+        if (lane16 == 1 && p.ddelta_bias) atomicAdd(&p.ddelta_bias[d], sBias);
+      }
+      // hand this chunk's first delta to the chunk on the left
+      if (c > 0 && lane16 == 0) sDf[slot] = dl[0];
+    }
+
+    __syncthreads();
+    // flush the chunk's dB / dC tile
+    for (int i = threadIdx.x; i < 2 * N * LC; i += kScanThreads) {
+      const int tensor = i / (N * LC);
+      const int rem = i - tensor * (N * LC);
+      const int n = rem / LC, t = rem - n * LC;
+      const int gt = c * LC + t;
+      if (gt < L) {
+        float* dst = (tensor == 0 ? p.dB : p.dC) + (static_cast<size_t>(b) * N + n) * L + gt;
+        atomicAdd(dst, sAcc[(tensor * kMaxState + n) * LC + t]);
+      }
+    }
+  }
+}
+
+static size_t bwd_smem_bytes(int kItems, int passes) {
+  const int LC = 16 * kItems;
+  return sizeof(float) * (2 * kMaxState * (LC + 4) + 2 * kMaxState * LC + kRowsPerPass * passes * kMaxState +
+                          kRowsPerPass * passes);
+}
+
+template <typename T>
+static int launch_bwd(const ScanArgs& a, hipStream_t s) {
+  dim3 grid((a.dim + kRowsPerPass * a.passes - 1) / (kRowsPerPass * a.passes), a.batch);
+  if (a.seqlen <= 64) {
+    hipLaunchKernelGGL((scan_bwd_kernel<T, 4>), grid, dim3(kScanThreads), bwd_smem_bytes(4, a.passes), s, a);
+  } else {
+    hipLaunchKernelGGL((scan_bwd_kernel<T, 8>), grid, dim3(kScanThreads), bwd_smem_bytes(8, a.passes), s, a);
+  }
+  return static_cast<int>(hipGetLastError());
+}
+
+}  // namespace simamba
+
+using namespace simamba;
+
+static bool aligned16b(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+extern "C" int simamba_selective_scan_bwd(const void* u, const void* delta, const float* A, const void* B,
+                                          const void* C, const float* D, const void* z,
+                                          const float* delta_bias, const void* dout, const float* x_ckpt,
+                                          void* du, void* ddelta, float* dA, float* dB, float* dC, float* dD,
+                                          void* dz, float* ddelta_bias, int batch, int dim, int seqlen,
+                                          int dstate, int io_dtype, int delta_softplus, void* stream) {
+  if (!u || !delta || !A || !B || !C || !dout || !du || !ddelta || !dA || !dB || !dC) return SIMAMBA_E_NULLPTR;
+  if ((z != nullptr) != (dz != nullptr)) return SIMAMBA_E_NULLPTR;
+  if (batch < 0 || dim <= 0 || seqlen < 0 || batch > 65535) return SIMAMBA_E_SHAPE;
+  if (dstate < 1 || dstate > kMaxState) return SIMAMBA_E_DSTATE;
+  if (io_dtype != SIMAMBA_F32 && io_dtype != SIMAMBA_BF16) return SIMAMBA_E_DTYPE;
+  const int nchunks = simamba_scan_num_chunks(seqlen);
+  if (nchunks > 1 && !x_ckpt) return SIMAMBA_E_NULLPTR;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipError_t e;
+  if ((e = hipMemsetAsync(dA, 0, sizeof(float) * dim * dstate, s)) != hipSuccess) return static_cast<int>(e);
+  const size_t bc = sizeof(float) * static_cast<size_t>(batch) * dstate * seqlen;
+  if (bc) {
+    if ((e = hipMemsetAsync(dB, 0, bc, s)) != hipSuccess) return static_cast<int>(e);
+    if ((e = hipMemsetAsync(dC, 0, bc, s)) != hipSuccess) return static_cast<int>(e);
+  }
+  if (dD && (e = hipMemsetAsync(dD, 0, sizeof(float) * dim, s)) != hipSuccess) return static_cast<int>(e);
+  if (ddelta_bias && (e = hipMemsetAsync(ddelta_bias, 0, sizeof(float) * dim, s)) != hipSuccess)
+    return static_cast<int>(e);
+  if (batch == 0 || seqlen == 0) return SIMAMBA_OK;
+  ScanArgs a{};
+  a.u = u; a.delta = delta; a.A = A; a.B = B; a.C = C; a.D = D; a.z = z; a.delta_bias = delta_bias;
+  a.dout = dout; a.x_ckpt = const_cast<float*>(x_ckpt);
+  a.du = du; a.ddelta = ddelta; a.dA = dA; a.dB = dB; a.dC = dC; a.dD = dD; a.dz = dz;
+  a.ddelta_bias = ddelta_bias;
+  a.batch = batch; a.dim = dim; a.seqlen = seqlen; a.dstate = dstate;
+  a.nchunks = nchunks;
+  a.softplus = delta_softplus;
+  const size_t esz = io_dtype == SIMAMBA_F32 ? 4 : 2;
+  a.vec = ((seqlen * esz) % 16 == 0) && aligned16b(u) && aligned16b(delta) && aligned16b(dout) &&
+          aligned16b(du) && aligned16b(ddelta) && (!z || (aligned16b(z) && aligned16b(dz)));
+  int passes = 4;
+  while (passes > 1 && static_cast<long long>(batch) * ((dim + 16 * passes - 1) / (16 * passes)) < 768) passes >>= 1;
+  a.passes = passes;
+  return io_dtype == SIMAMBA_F32 ? launch_bwd<float>(a, s) : launch_bwd<bf16_t>(a, s);
+}

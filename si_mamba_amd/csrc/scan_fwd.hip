@@ -1,0 +1,171 @@
+// Selective-scan forward for gfx950.  Decomposition: see scan_common.h.
+//
+// Replaces selective_scan_cuda.fwd of mamba-ssm as reached from the reference's
+// models/block.py:72.  Algorithmic HBM bytes: 4*B*D*L*s (u, delta, z, out) + 2*B*N*L*s (B, C)
+// + small; the (B_t, C_t) tile is re-read from L2 once per 16*R channels.
+#include "scan_common.h"
+
+namespace simamba {
+
+template <typename T, int kItems>
+__global__ __launch_bounds__(kScanThreads) void scan_fwd_kernel(ScanArgs p) {
+  constexpr int LC = 16 * kItems;
+  constexpr int LDP = LC + 4;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sB = smem;                       // [kMaxState][LDP]
+  float* sC = sB + kMaxState * LDP;       // [kMaxState][LDP]
+  float* sCarry = sC + kMaxState * LDP;   // [16 * passes][kMaxState]
+
+  const int b = blockIdx.y;
+  const int tile_base = blockIdx.x * (kRowsPerPass * p.passes);
+  const int lane16 = threadIdx.x & 15;
+  const int rowslot = threadIdx.x >> 4;   // 0..15: wave*4 + sub-row
+  const int L = p.seqlen, D = p.dim, N = p.dstate;
+  const T* __restrict__ ug = static_cast<const T*>(p.u);
+  const T* __restrict__ dg = static_cast<const T*>(p.delta);
+  const T* __restrict__ zg = static_cast<const T*>(p.z);
+  T* __restrict__ og = static_cast<T*>(p.out);
+  const bool vec = p.vec != 0;
+  const bool keep_state = (p.nchunks > 1) || p.x_ckpt || p.last_state;
+
+  for (int c = 0; c < p.nchunks; ++c) {
+    __syncthreads();
+    stage_bc<T, LC>(static_cast<const T*>(p.B), static_cast<const T*>(p.C), sB, sC, b, N, L, c);
+    __syncthreads();
+
+    for (int r = 0; r < p.passes; ++r) {
+      const int slot = r * kRowsPerPass + rowslot;
+      const int d = tile_base + slot;
+      const bool dvalid = d < D;
+      const int dc = dvalid ? d : D - 1;
+      const int t0 = c * LC + lane16 * kItems;
+      int nvalid = L - t0;
+      nvalid = nvalid < 0 ? 0 : (nvalid > kItems ? kItems : nvalid);
+      const size_t off = (static_cast<size_t>(b) * D + dc) * L + t0;
+
+      float u[kItems], dl[kItems], zz[kItems], y[kItems], du[kItems];
+      load_items<T, kItems>(ug + off, nvalid, vec, u);
+      load_items<T, kItems>(dg + off, nvalid, vec, dl);
+      if (zg) load_items<T, kItems>(zg + off, nvalid, vec, zz);
+
+      const float bias = p.delta_bias ? p.delta_bias[dc] : 0.f;
+      const float Dd = p.D ? p.D[dc] : 0.f;
+      float sumd = 0.f;
+#pragma unroll
+      for (int i = 0; i < kItems; ++i) {
+        float x = dl[i] + bias;
+        x = p.softplus ? softplus_f(x) : x;
+        x = (i < nvalid) ? x : 0.f;           // padded steps are the identity map
+        dl[i] = x;
+        sumd += x;
+        du[i] = x * u[i];
+        y[i] = Dd * u[i];
+      }
+
+      const float* __restrict__ Arow = p.A + static_cast<size_t>(dc) * N;
+      for (int n = 0; n < N; ++n) {
+        const float A2 = Arow[n] * kLog2e;
+        const float* bp = sB + n * LDP + lane16 * kItems;
+        const float* cp = sC + n * LDP + lane16 * kItems;
+        float a[kItems], bb[kItems], cc[kItems];
+#pragma unroll
+        for (int i = 0; i < kItems; i += 4) {
+          float4 vb = *reinterpret_cast<const float4*>(bp + i);
+          float4 vc = *reinterpret_cast<const float4*>(cp + i);
+          bb[i] = vb.x; bb[i + 1] = vb.y; bb[i + 2] = vb.z; bb[i + 3] = vb.w;
+          cc[i] = vc.x; cc[i + 1] = vc.y; cc[i + 2] = vc.z; cc[i + 3] = vc.w;
+        }
+        float S = 0.f;
+#pragma unroll
+        for (int i = 0; i < kItems; ++i) {
+          a[i] = fast_exp2(dl[i] * A2);
+          bb[i] = du[i] * bb[i];
+          S = fmaf(a[i], S, bb[i]);
+        }
+        float P = fast_exp2(A2 * sumd);
+        row_scan_inclusive(P, S);
+        const float Pex = dpp<DPP_ROW_SHR + 1>(1.f, P);
+        const float Sex = dpp<DPP_ROW_SHR + 1>(0.f, S);
+        const float carry = (c > 0) ? sCarry[slot * kMaxState + n] : 0.f;
+        float h = fmaf(Pex, carry, Sex);
+        if (keep_state && lane16 == 15) sCarry[slot * kMaxState + n] = fmaf(P, carry, S);
+#pragma unroll
+        for (int i = 0; i < kItems; ++i) {
+          h = fmaf(a[i], h, bb[i]);
+          y[i] = fmaf(cc[i], h, y[i]);
+        }
+      }
+
+      if (zg) {
+#pragma unroll
+        for (int i = 0; i < kItems; ++i) y[i] = y[i] * zz[i] * sigmoid_f(zz[i]);
+      }
+      if (dvalid) store_items<T, kItems>(og + off, nvalid, vec, y);
+
+      if (keep_state) {
+        __builtin_amdgcn_wave_barrier();
+        if (dvalid && lane16 < N) {
+          const float st = sCarry[slot * kMaxState + lane16];
+          if (p.x_ckpt)
+            p.x_ckpt[((static_cast<size_t>(b) * D + d) * p.nchunks + c) * N + lane16] = st;
+          if (p.last_state && c == p.nchunks - 1)
+            p.last_state[(static_cast<size_t>(b) * D + d) * N + lane16] = st;
+        }
+      }
+    }
+  }
+}
+
+static size_t fwd_smem_bytes(int kItems, int passes) {
+  const int LC = 16 * kItems;
+  return sizeof(float) * (2 * kMaxState * (LC + 4) + kRowsPerPass * passes * kMaxState);
+}
+
+template <typename T>
+static int launch_fwd(const ScanArgs& a, hipStream_t s) {
+  dim3 grid((a.dim + kRowsPerPass * a.passes - 1) / (kRowsPerPass * a.passes), a.batch);
+  if (a.seqlen <= 64) {
+    hipLaunchKernelGGL((scan_fwd_kernel<T, 4>), grid, dim3(kScanThreads), fwd_smem_bytes(4, a.passes), s, a);
+  } else {
+    hipLaunchKernelGGL((scan_fwd_kernel<T, 8>), grid, dim3(kScanThreads), fwd_smem_bytes(8, a.passes), s, a);
+  }
+  return static_cast<int>(hipGetLastError());
+}
+
+}  // namespace simamba
+
+using namespace simamba;
+
+extern "C" int simamba_scan_num_chunks(int seqlen) {
+  if (seqlen <= 64) return 1;
+  return (seqlen + SIMAMBA_SCAN_CHUNK - 1) / SIMAMBA_SCAN_CHUNK;
+}
+
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+extern "C" int simamba_selective_scan_fwd(const void* u, const void* delta, const float* A, const void* B,
+                                          const void* C, const float* D, const void* z,
+                                          const float* delta_bias, void* out, float* x_ckpt,
+                                          float* last_state, int batch, int dim, int seqlen, int dstate,
+                                          int io_dtype, int delta_softplus, void* stream) {
+  if (!u || !delta || !A || !B || !C || !out) return SIMAMBA_E_NULLPTR;
+  if (batch < 0 || dim <= 0 || seqlen < 0 || batch > 65535) return SIMAMBA_E_SHAPE;
+  if (dstate < 1 || dstate > kMaxState) return SIMAMBA_E_DSTATE;
+  if (io_dtype != SIMAMBA_F32 && io_dtype != SIMAMBA_BF16) return SIMAMBA_E_DTYPE;
+  if (batch == 0 || seqlen == 0) return SIMAMBA_OK;
+  ScanArgs a{};
+  a.u = u; a.delta = delta; a.A = A; a.B = B; a.C = C; a.D = D; a.z = z; a.delta_bias = delta_bias;
+  a.out = out; a.x_ckpt = x_ckpt; a.last_state = last_state;
+  a.batch = batch; a.dim = dim; a.seqlen = seqlen; a.dstate = dstate;
+  a.nchunks = simamba_scan_num_chunks(seqlen);
+  a.softplus = delta_softplus;
+  const size_t esz = io_dtype == SIMAMBA_F32 ? 4 : 2;
+  a.vec = ((seqlen * esz) % 16 == 0) && aligned16(u) && aligned16(delta) && aligned16(out) &&
+          (!z || aligned16(z));
+  // channels per workgroup: amortise the (B_t,C_t) staging, but keep >= ~3 workgroups per CU
+  int passes = 4;
+  while (passes > 1 && static_cast<long long>(batch) * ((dim + 16 * passes - 1) / (16 * passes)) < 768) passes >>= 1;
+  a.passes = passes;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return io_dtype == SIMAMBA_F32 ? launch_fwd<float>(a, s) : launch_fwd<bf16_t>(a, s);
+}

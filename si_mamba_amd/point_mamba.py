@@ -1,0 +1,153 @@
+"""Caller of the hot path: the reference's ``PointMamba`` classifier, canonical SAST route.
+
+Mirrors reference models/point_mamba.py ``PointMamba`` (:431-562 constructor, :843-1125 forward with
+``method == "SAST"``, ``use_wavelets=False``, ``tau=None``) with the parameter names and shapes of the
+reference's own checkpoint table (logs/finetuned_hardest.log:100-426, 12.29 M parameters), so a
+reference state_dict loads unchanged.  What runs on the HIP kernels: the spectral ordering
+(``spectral.spectral_order``) and every Mamba mixer of ``blocks``.
+
+``Group`` (farthest-point sampling + k-NN grouping) and ``Encoder`` (mini-PointNet) sit BEFORE the
+hot path ("next" row 1).  The reference gets FPS / k-NN from pytorch3d CUDA ops
+(:93, :96), which are absent here; ``Group`` below is a plain-torch stand-in used by the
+benchmark / test harness only, and is not part of the graded path.
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+
+import torch
+import torch.nn as nn
+
+from . import spectral
+from .block import MixerModel
+
+
+def farthest_point_sample(xyz, K):
+    """Iterative FPS started at index 0 (pytorch3d.sample_farthest_points default, :93)."""
+    B, N, _ = xyz.shape
+    idx = torch.zeros(B, K, dtype=torch.long, device=xyz.device)
+    mind = torch.full((B, N), float("inf"), device=xyz.device, dtype=xyz.dtype)
+    cur = torch.zeros(B, dtype=torch.long, device=xyz.device)
+    ar = torch.arange(B, device=xyz.device)
+    for i in range(K):
+        idx[:, i] = cur
+        d = ((xyz - xyz[ar, cur][:, None, :]) ** 2).sum(-1)
+        mind = torch.minimum(mind, d)
+        cur = mind.argmax(dim=1)
+    return idx
+
+
+class Group(nn.Module):
+    """(B,N,3) -> neighborhood (B,G,M,3) centred, center (B,G,3), neighborhood_org; reference :76-111."""
+
+    def __init__(self, num_group, group_size):
+        super().__init__()
+        self.num_group = num_group
+        self.group_size = group_size
+
+    @torch.no_grad()
+    def _indices(self, xyz):
+        cidx = farthest_point_sample(xyz, self.num_group)
+        center = torch.gather(xyz, 1, cidx.unsqueeze(-1).expand(-1, -1, 3))
+        d = torch.cdist(center, xyz)
+        nn_idx = d.topk(self.group_size, dim=-1, largest=False, sorted=False)[1]
+        return center, nn_idx
+
+    def forward(self, xyz):
+        B, N, _ = xyz.shape
+        center, nn_idx = self._indices(xyz)
+        flat = (nn_idx + torch.arange(B, device=xyz.device).view(-1, 1, 1) * N).view(-1)
+        nb = xyz.reshape(B * N, -1)[flat].view(B, self.num_group, self.group_size, 3).contiguous()
+        return nb - center.unsqueeze(2), center, nb
+
+
+class Encoder(nn.Module):
+    """Mini-PointNet patch embedding; reference :42-73 (same layer names)."""
+
+    def __init__(self, encoder_channel):
+        super().__init__()
+        self.encoder_channel = encoder_channel
+        self.first_conv = nn.Sequential(nn.Conv1d(3, 128, 1), nn.BatchNorm1d(128), nn.ReLU(inplace=True),
+                                        nn.Conv1d(128, 256, 1))
+        self.second_conv = nn.Sequential(nn.Conv1d(512, 512, 1), nn.BatchNorm1d(512), nn.ReLU(inplace=True),
+                                         nn.Conv1d(512, self.encoder_channel, 1))
+
+    def forward(self, point_groups):
+        bs, g, n, _ = point_groups.shape
+        f = self.first_conv(point_groups.reshape(bs * g, n, 3).transpose(2, 1))
+        fg = torch.max(f, dim=2, keepdim=True)[0]
+        f = self.second_conv(torch.cat([fg.expand(-1, -1, n), f], dim=1))
+        return torch.max(f, dim=2, keepdim=False)[0].reshape(bs, g, self.encoder_channel)
+
+
+def default_config(**over):
+    """cfgs/finetune_scan_hardest.yaml:22-49 (the config the 12.29 M parameter table belongs to)."""
+    cfg = dict(trans_dim=384, depth=12, cls_dim=15, group_size=32, num_group=128, encoder_dims=384,
+               rms_norm=False, drop_path=0.1, drop_out=0., method="SAST", reverse=True, knn_graph=20,
+               k_top_eigenvectors=4, alpha=10., smallest=True, symmetric=True, self_loop=False,
+               binary=True, matrix="laplacian")
+    cfg.update(over)
+    return SimpleNamespace(**cfg)
+
+
+class PointMamba(nn.Module):
+    def __init__(self, config, **kwargs):
+        super().__init__()
+        self.config = config
+        self.trans_dim = config.trans_dim
+        self.depth = config.depth
+        self.cls_dim = config.cls_dim
+        self.group_size = config.group_size
+        self.num_group = config.num_group
+        self.encoder_dims = config.encoder_dims
+        self.group_divider = Group(num_group=self.num_group, group_size=self.group_size)
+        self.encoder = Encoder(encoder_channel=self.encoder_dims)
+        self.drop_path = getattr(config, "drop_path", 0.)
+        self.rms_norm = getattr(config, "rms_norm", False)
+        self.drop_out_in_block = getattr(config, "drop_out_in_block", 0.)
+        self.pos_embed = nn.Sequential(nn.Linear(3, 128), nn.GELU(), nn.Linear(128, self.trans_dim))
+        self.blocks = MixerModel(d_model=self.trans_dim, n_layer=self.depth, rms_norm=self.rms_norm,
+                                 drop_out_in_block=self.drop_out_in_block, drop_path=self.drop_path)
+        self.norm = nn.LayerNorm(self.trans_dim)
+        self.cls_head_finetune = nn.Sequential(
+            nn.Linear(self.trans_dim, 256), nn.BatchNorm1d(256), nn.ReLU(inplace=True), nn.Dropout(0.5),
+            nn.Linear(256, 256), nn.BatchNorm1d(256), nn.ReLU(inplace=True), nn.Dropout(0.5),
+            nn.Linear(256, self.cls_dim))
+        self.loss_ce = nn.CrossEntropyLoss()
+        self.drop_out = nn.Dropout(getattr(config, "drop_out", 0.))
+        self.method = config.method
+        self.reverse = config.reverse
+        self.k_top_eigenvectors = config.k_top_eigenvectors
+        self.smallest = config.smallest
+        self.knn_graph = config.knn_graph
+        self.symmetric = config.symmetric
+        self.self_loop = config.self_loop
+        self.alpha = config.alpha
+        self.binary = config.binary
+        self.matrix = config.matrix
+        if self.method != "SAST":
+            raise NotImplementedError("only the canonical SAST route is built (SURVEY.md headline 3)")
+
+    def get_loss_acc(self, ret, gt):
+        loss = self.loss_ce(ret, gt.long())
+        pred = ret.argmax(-1)
+        acc = (pred == gt).sum() / float(gt.size(0))
+        return loss, acc * 100
+
+    def order_tokens(self, tokens, pos, center):
+        """reference :872-898 + :982-989: spectral ordering of (tokens, pos)."""
+        _, _, order = spectral.spectral_order(center, self.knn_graph, self.alpha, self.k_top_eigenvectors,
+                                              smallest=self.smallest, symmetric=self.symmetric,
+                                              self_loop=self.self_loop, binary=self.binary,
+                                              matrix=self.matrix)
+        return spectral.sast_gather(tokens, pos, order, reverse=self.reverse)
+
+    def forward(self, pts, gt=None):
+        neighborhood, center, _ = self.group_divider(pts)
+        tokens = self.encoder(neighborhood)
+        pos = self.pos_embed(center)
+        x, pos = self.order_tokens(tokens, pos, center)
+        x = self.drop_out(x)
+        x = self.blocks(x, pos)
+        x = self.norm(x)
+        return self.cls_head_finetune(x.mean(1))

@@ -1,0 +1,119 @@
+"""selective_scan_fn on the MI355X kernels.
+
+Mirrors the operator the reference's mixer uses
+(``mamba_ssm.ops.selective_scan_interface.selective_scan_fn``; reached from
+reference models/block.py:72 through the Mamba built at models/point_mamba.py:162):
+same argument names, meaning and return values.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+
+
+def _bc_bnl(M, name):
+    if M.dim() == 4:
+        if M.shape[1] != 1:
+            raise ValueError(f"{name}: only ngroups == 1 is supported (got {tuple(M.shape)})")
+        return M[:, 0], True
+    if M.dim() != 3:
+        raise ValueError(f"{name} must be (batch, dstate, seqlen) or (batch, 1, dstate, seqlen)")
+    return M, False
+
+
+class SelectiveScanFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, u, delta, A, B, C, D=None, z=None, delta_bias=None,
+                delta_softplus=False, return_last_state=False):
+        _lib.require_gpu(u, "selective_scan_fn")
+        lib = _lib.load()
+        io = u.dtype
+        code = _lib.dtype_code(io)
+        if A.is_complex():
+            raise NotImplementedError("complex A is not on the SI-Mamba path")
+        B3, ctx.b_grouped = _bc_bnl(B, "B")
+        C3, ctx.c_grouped = _bc_bnl(C, "C")
+        batch, dim, L = u.shape
+        N = A.shape[1]
+        if A.shape[0] != dim or B3.shape != (batch, N, L) or C3.shape != (batch, N, L):
+            raise ValueError("selective_scan_fn: inconsistent shapes")
+        uc = u.contiguous()
+        dc = delta.to(io).contiguous()
+        Ac = A.float().contiguous()
+        Bc = B3.to(io).contiguous()
+        Cc = C3.to(io).contiguous()
+        Dc = None if D is None else D.float().contiguous()
+        zc = None if z is None else z.to(io).contiguous()
+        bc = None if delta_bias is None else delta_bias.float().contiguous()
+        out = torch.empty_like(uc)
+        nchunks = lib.simamba_scan_num_chunks(L)
+        needs_grad = any(t is not None and t.requires_grad for t in (u, delta, A, B, C, D, z, delta_bias))
+        x_ckpt = (torch.empty(batch, dim, nchunks, N, device=u.device, dtype=torch.float32)
+                  if (needs_grad and nchunks > 1) else None)
+        last = (torch.empty(batch, dim, N, device=u.device, dtype=torch.float32)
+                if return_last_state else None)
+        with torch.cuda.device(u.device), _lib.timed("scan_fwd", u.device):
+            rc = lib.simamba_selective_scan_fwd(
+                _lib.ptr(uc), _lib.ptr(dc), _lib.ptr(Ac), _lib.ptr(Bc), _lib.ptr(Cc), _lib.ptr(Dc),
+                _lib.ptr(zc), _lib.ptr(bc), _lib.ptr(out), _lib.ptr(x_ckpt), _lib.ptr(last),
+                batch, dim, L, N, code, int(bool(delta_softplus)), _lib.stream_ptr(u.device))
+        _lib.check(rc, "simamba_selective_scan_fwd")
+        ctx.delta_softplus = bool(delta_softplus)
+        ctx.has = (D is not None, z is not None, delta_bias is not None)
+        ctx.in_dtypes = (delta.dtype, B.dtype, C.dtype,
+                         None if D is None else D.dtype,
+                         None if z is None else z.dtype,
+                         None if delta_bias is None else delta_bias.dtype, A.dtype)
+        ctx.save_for_backward(uc, dc, Ac, Bc, Cc, Dc, zc, bc, x_ckpt)
+        if return_last_state:
+            ctx.mark_non_differentiable(last)
+            return out, last
+        return out
+
+    @staticmethod
+    def backward(ctx, dout, *unused):
+        uc, dc, Ac, Bc, Cc, Dc, zc, bc, x_ckpt = ctx.saved_tensors
+        lib = _lib.load()
+        batch, dim, L = uc.shape
+        N = Ac.shape[1]
+        io = uc.dtype
+        dout = dout.to(io).contiguous()
+        du = torch.empty_like(uc)
+        ddelta = torch.empty_like(uc)
+        dz = torch.empty_like(uc) if zc is not None else None
+        f32 = dict(device=uc.device, dtype=torch.float32)
+        dA = torch.empty(dim, N, **f32)
+        dB = torch.empty(batch, N, L, **f32)
+        dC = torch.empty(batch, N, L, **f32)
+        dD = torch.empty(dim, **f32) if Dc is not None else None
+        dbias = torch.empty(dim, **f32) if bc is not None else None
+        with torch.cuda.device(uc.device), _lib.timed("scan_bwd", uc.device):
+            rc = lib.simamba_selective_scan_bwd(
+                _lib.ptr(uc), _lib.ptr(dc), _lib.ptr(Ac), _lib.ptr(Bc), _lib.ptr(Cc), _lib.ptr(Dc),
+                _lib.ptr(zc), _lib.ptr(bc), _lib.ptr(dout), _lib.ptr(x_ckpt),
+                _lib.ptr(du), _lib.ptr(ddelta), _lib.ptr(dA), _lib.ptr(dB), _lib.ptr(dC), _lib.ptr(dD),
+                _lib.ptr(dz), _lib.ptr(dbias), batch, dim, L, N, _lib.dtype_code(io),
+                int(ctx.delta_softplus), _lib.stream_ptr(uc.device))
+        _lib.check(rc, "simamba_selective_scan_bwd")
+        dt_delta, dt_B, dt_C, dt_D, dt_z, dt_bias, dt_A = ctx.in_dtypes
+        dB = dB.to(dt_B)
+        dC = dC.to(dt_C)
+        if ctx.b_grouped:
+            dB = dB.unsqueeze(1)
+        if ctx.c_grouped:
+            dC = dC.unsqueeze(1)
+        return (du, ddelta.to(dt_delta), dA.to(dt_A), dB, dC,
+                None if dD is None else dD.to(dt_D),
+                None if dz is None else dz.to(dt_z),
+                None if dbias is None else dbias.to(dt_bias),
+                None, None)
+
+
+def selective_scan_fn(u, delta, A, B, C, D=None, z=None, delta_bias=None,
+                      delta_softplus=False, return_last_state=False):
+    """u, delta, z: (B, D, L); A: (D, N); B, C: (B, N, L) or (B, 1, N, L); D, delta_bias: (D).
+
+    Returns out (B, D, L) in u's dtype, plus last_state (B, D, N) fp32 when asked.
+    """
+    return SelectiveScanFn.apply(u, delta, A, B, C, D, z, delta_bias, delta_softplus, return_last_state)

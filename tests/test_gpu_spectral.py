@@ -1,0 +1,138 @@
+"""GPU parity: k-NN graph, Laplacian eigen-decomposition and orderings vs the CPU oracle.
+
+Integer / index work is bit-exact: the adjacency pattern, and every position of an ordering whose
+neighbouring eigenvector entries are further apart than the fp32 eigensolver error.  Eigenvectors are
+compared up to sign: LAPACK (the oracle), cuSOLVER (the reference on CUDA) and this Jacobi solver are
+each free to pick it.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import spectral_ref as sr
+from oracle.gen_golden import SPECTRAL_COMBOS, unit_ball_centers
+
+pytestmark = pytest.mark.gpu
+
+
+def align_sign(got, want):
+    """flip each got[:, :, i] to the sign that best matches want[:, :, i]"""
+    s = torch.sign((got * want).sum(dim=1, keepdim=True))
+    s[s == 0] = 1
+    return got * s, s
+
+
+@pytest.mark.parametrize("name", ["spectral_g64", "spectral_g128"])
+def test_graph_adjacency_bit_exact(name, device):
+    from si_mamba_amd import spectral
+    g = load_golden(name)
+    c = torch.from_numpy(g["centers"]).to(device)
+    for cb in SPECTRAL_COMBOS:
+        adj = spectral.create_graph_from_feature_space_gpu_weighted_adjacency(
+            c, cb["knn"], cb["alpha"], cb["symmetric"], cb["self_loop"], cb["binary"]).cpu().numpy()
+        want = g[f"{cb['tag']}.adj"]
+        np.testing.assert_array_equal(adj != 0, want != 0)                 # same edges, exactly
+        np.testing.assert_allclose(adj, want, rtol=3e-7, atol=0)           # weights: device expf vs libm
+    adj0 = spectral.create_graph_from_centers(c, 10, 0.0, True, True, False).cpu().numpy()
+    np.testing.assert_array_equal(adj0 != 0, g["sigma_mean.adj"] != 0)
+    np.testing.assert_allclose(adj0, g["sigma_mean.adj"], rtol=2e-6, atol=0)
+
+
+@pytest.mark.parametrize("name", ["spectral_g64", "spectral_g128"])
+def test_eigenpairs_and_orders(name, device):
+    from si_mamba_amd import spectral
+    g = load_golden(name)
+    exact_total, exact_hit = 0, 0
+    for cb in SPECTRAL_COMBOS:
+        t = cb["tag"]
+        adj = torch.from_numpy(g[f"{t}.adj"]).to(device)
+        vals, vecs, all_vals, all_vecs = spectral.calc_top_k_eigenvalues_eigenvectors(adj, 4, True)
+        wvals, wvecs = torch.from_numpy(g[f"{t}.vals"]), torch.from_numpy(g[f"{t}.vecs"])
+        np.testing.assert_allclose(vals.cpu().numpy(), wvals.numpy(), atol=2e-5)
+        np.testing.assert_allclose(all_vals.cpu().numpy(), g[f"{t}.all_vals"], atol=2e-5)
+        gv, sgn = align_sign(vecs.cpu(), wvecs)
+        gaps = torch.from_numpy(g[f"{t}.all_vals"])
+        # eigenvector error scales with 1/gap to the neighbouring eigenvalue
+        lam_gap = torch.minimum((gaps[:, 1:5] - gaps[:, 0:4]).abs(),
+                                torch.cat([torch.full((gaps.shape[0], 1), 1.0), (gaps[:, 1:4] - gaps[:, 0:3]).abs()], 1))
+        err = (gv - wvecs).abs().amax(dim=1)
+        assert (err * lam_gap).max() < 2e-5, (t, err.max().item())
+        # orthonormal basis, small residual against the matrix eigh actually decomposes
+        S = sr.eigh_lower(sr.rw_laplacian(torch.from_numpy(g[f"{t}.adj"])))
+        av = all_vecs.cpu()
+        eye = torch.eye(av.shape[1])
+        assert (av.transpose(1, 2) @ av - eye).abs().max() < 2e-5
+        assert (S @ av - av * all_vals.cpu()[:, None, :]).abs().max() < 2e-5
+        # ordering parity: exact wherever the oracle's own neighbouring gaps exceed the solver error
+        order = spectral.argsort_rows((vecs * sgn.to(device)).transpose(1, 2).reshape(-1, vecs.shape[1]))
+        order = order.view(vecs.shape[0], 4, -1).cpu()
+        worder = torch.from_numpy(g[f"{t}.order"])
+        wsorted = torch.gather(wvecs.transpose(1, 2), 2, worder)
+        gapl = torch.cat([torch.full_like(wsorted[..., :1], 1.0), wsorted[..., 1:] - wsorted[..., :-1]], -1)
+        gapr = torch.cat([wsorted[..., 1:] - wsorted[..., :-1], torch.full_like(wsorted[..., :1], 1.0)], -1)
+        tau = 4.0 * err[:, :, None].clamp_min(1e-6)
+        safe = (gapl > tau) & (gapr > tau)
+        assert torch.equal(order[safe], worder[safe]), t
+        exact_total += order.numel()
+        exact_hit += (order == worder).sum().item()
+    print(f"{name}: exact order positions {exact_hit}/{exact_total}")
+    assert exact_hit / exact_total > 0.97
+
+
+def test_symmetric_and_largest_modes(device):
+    from si_mamba_amd import spectral
+    g = load_golden("spectral_g64")
+    adj = torch.from_numpy(g["hardest.adj"]).to(device)
+    v, e, _, _ = spectral.calc_top_k_eigenvalues_eigenvectors_symmetric(adj, 4, True)
+    np.testing.assert_allclose(v.cpu().numpy(), g["hardest.sym.vals"], atol=2e-5)
+    ge, _ = align_sign(e.cpu(), torch.from_numpy(g["hardest.sym.vecs"]))
+    assert (ge - torch.from_numpy(g["hardest.sym.vecs"])).abs().max() < 5e-3
+    v, e, _, _ = spectral.calc_top_k_eigenvalues_eigenvectors(adj, 4, False)
+    np.testing.assert_allclose(v.cpu().numpy(), g["hardest.largest.vals"], atol=2e-5)
+
+
+def test_fused_order_equals_unfused_and_gather(device):
+    from si_mamba_amd import spectral
+    c = unit_ball_centers(8, 128, 5).to(device)
+    vals, vecs, order = spectral.spectral_order(c, 20, 10.0, 4, smallest=True, symmetric=True,
+                                                self_loop=False, binary=True)
+    adj = spectral.create_graph_from_feature_space_gpu_weighted_adjacency(c, 20, 10.0, True, False, True)
+    v2, e2, _, _ = spectral.calc_top_k_eigenvalues_eigenvectors(adj, 4, True)
+    assert torch.equal(vals, v2) and torch.equal(vecs, e2)
+    for i in range(4):
+        assert torch.equal(order[:, i], spectral.argsort_rows(vecs[:, :, i].contiguous()))
+    # each order is a permutation that sorts its eigenvector
+    assert torch.equal(order.sort(dim=2)[0], torch.arange(128, device=device).expand(8, 4, 128))
+    sv = torch.gather(vecs.transpose(1, 2), 2, order)
+    assert (sv[..., 1:] >= sv[..., :-1]).all()
+    tokens, pos = torch.randn(8, 128, 384, device=device), torch.randn(8, 128, 384, device=device)
+    x, p = spectral.sast_gather(tokens, pos, order, reverse=True)
+    wx, wp = sr.sast_assemble(tokens.cpu(), pos.cpu(), vecs.cpu(), reverse=True)
+    assert x.shape == (8, 1024, 384)
+    assert torch.equal(x.cpu(), wx) and torch.equal(p.cpu(), wp)
+    one = spectral.sort_points_by_fiedler(tokens, vecs[:, :, 1].contiguous())
+    assert torch.equal(one.cpu(), sr.sort_points_by_fiedler(tokens.cpu(), vecs[:, :, 1].cpu()))
+
+
+def test_full_batch_properties(device):
+    """BASELINE config 3 size (B=128, G=128): solver invariants that do not need the oracle."""
+    from si_mamba_amd import spectral
+    c = unit_ball_centers(128, 128, 9).to(device)
+    adj = spectral.create_graph_from_feature_space_gpu_weighted_adjacency(c, 20, 10.0, True, False, True)
+    assert torch.equal(adj, adj.transpose(1, 2)) and (adj.sum(-1) >= 20).all()
+    vals, vecs, all_vals, all_vecs = spectral.calc_top_k_eigenvalues_eigenvectors(adj, 4, True)
+    eye = torch.eye(128, device=device)
+    assert (all_vecs.transpose(1, 2) @ all_vecs - eye).abs().max() < 3e-5
+    S = sr.eigh_lower(sr.rw_laplacian(adj.cpu())).to(device)
+    assert (S @ all_vecs - all_vecs * all_vals[:, None, :]).abs().max() < 3e-5
+    assert (all_vals[:, 1:] >= all_vals[:, :-1]).all()
+    assert torch.equal(vals, all_vals[:, :4])
+    # trace is preserved by the rotations
+    assert (all_vals.sum(1) - torch.diagonal(S, dim1=1, dim2=2).sum(1)).abs().max() < 1e-3
+
+
+def test_multilevel_travers_matches_oracle(device):
+    from si_mamba_amd import spectral
+    v = torch.randn(3, 64, 6)
+    assert torch.equal(spectral.multilevel_travers(v.to(device), 4).cpu(), sr.multilevel_travers(v, 4))
