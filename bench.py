@@ -1,0 +1,242 @@
+#!/usr/bin/env python3
+"""Headline benchmark: point-clouds/sec (fwd+bwd+optimizer) of the PointMamba classifier at
+B=64 per GPU, 1024 points -> 128 patches, d=384, 12 blocks (Mamba L = 1024), one process per GPU.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
+  roofline      selective-scan forward kernel inside the timed region: algorithmic bytes per launch /
+                mean launch duration from events recorded on the launch stream, vs 8 TB/s HBM.
+  cpu_baseline  the oracle (CPU restatement) running the same step on a 2-cloud sample on the host cores.
+plus "headline_scan" (the north-star micro-shape B=256, L=128, D=768, N=16, measured after the timed
+region) and "kernels" (mean ms per launch of every HIP kernel in the timed region).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+
+
+def scan_fwd_bytes(B, D, L, N, s=4):
+    """u, delta, z, out + B, C + A + D, bias."""
+    return 4 * B * D * L * s + 2 * B * N * L * s + 4 * D * N + 8 * D
+
+
+def scan_bwd_bytes(B, D, L, N, s=4):
+    return 7 * B * D * L * s + 2 * B * N * L * (s + 4) + 8 * D * N + 16 * D
+
+
+def make_clouds(B, N, seed, device):
+    g = torch.Generator().manual_seed(seed)
+    p = torch.randn(B, N, 3, generator=g)
+    p = p - p.mean(1, keepdim=True)                       # pc_norm (datasets/ShapeNet55Dataset.py:47-53)
+    p = p / p.norm(dim=-1).max(dim=1)[0][:, None, None]
+    return p.to(device)
+
+
+def traffic_from_profiles(kernel, shape):
+    """HBM bytes per launch from the committed rocprofv3 PMC summary, if one matches (else null)."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        rec = json.load(open(path))
+        return rec.get(f"{kernel}:{'x'.join(map(str, shape))}")
+    except Exception:
+        return None
+
+
+def cpu_baseline(npts, groups, seed=0):
+    """Oracle port of the same training step (same architecture, fp32) on a bounded 2-cloud sample."""
+    from oracle import scan_ref, spectral_ref
+    from si_mamba_amd.point_mamba import PointMamba, default_config
+    torch.manual_seed(0)
+    cfg = default_config(num_group=groups, drop_path=0.)
+    m = PointMamba(cfg)
+    for layer in m.blocks.layers:                          # CPU mixers: the oracle restatement
+        ref = scan_ref.MambaRef(cfg.trans_dim, layer_idx=layer.layer_idx)
+        ref.load_state_dict(layer.mixer.state_dict())
+        layer.mixer = ref
+
+    def order_tokens(tokens, pos, center):
+        adj = spectral_ref.create_graph_from_feature_space(center, cfg.knn_graph, cfg.alpha, cfg.symmetric,
+                                                           cfg.self_loop, cfg.binary)
+        _, vecs, _, _ = spectral_ref.calc_top_k_eigenvalues_eigenvectors(adj, cfg.k_top_eigenvectors, True)
+        return spectral_ref.sast_assemble(tokens, pos, vecs, reverse=True)
+
+    m.order_tokens = order_tokens
+    m.train()
+    B = 2
+    pts = make_clouds(B, npts, seed, "cpu")
+    gt = torch.randint(0, cfg.cls_dim, (B,))
+    t0 = time.perf_counter()
+    loss, _ = m.get_loss_acc(m(pts), gt)
+    loss.backward()
+    dt = time.perf_counter() - t0
+    return {"value": round(B / dt, 4), "unit": "point-clouds/s", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": f"{B} clouds, same 12-block d=384 model, fwd+bwd once, oracle mixers + torch.linalg.eigh "
+                      f"ordering ({dt:.1f} s)"}
+
+
+def headline_scan(device, iters=30):
+    """North-star micro-shape: scan fwd (and bwd) at (B,D,L,N) = (256,768,128,16), fp32."""
+    from oracle.gen_golden import scan_inputs
+    from si_mamba_amd import selective_scan_fn
+    B, D, L, N = 256, 768, 128, 16
+    t = {k: (v.to(device) if v is not None else None) for k, v in scan_inputs(B, D, L, N, seed=0).items()}
+    leaves = [t[k].requires_grad_(True) for k in ("u", "delta", "A", "B", "C", "D", "z", "delta_bias")]
+    res = {}
+    for mode in ("fwd", "bwd"):
+        times = []
+        for i in range(iters + 5):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            if mode == "fwd":
+                with torch.no_grad():
+                    a.record()
+                    selective_scan_fn(t["u"], t["delta"], t["A"], t["B"], t["C"], t["D"], t["z"], t["delta_bias"], True)
+                    b.record()
+            else:
+                out = selective_scan_fn(*leaves[:6], z=leaves[6], delta_bias=leaves[7], delta_softplus=True)
+                a.record()
+                torch.autograd.grad(out, leaves, t["dout"])
+                b.record()
+            torch.cuda.synchronize()
+            if i >= 5:
+                times.append(a.elapsed_time(b))
+        times.sort()
+        med = times[len(times) // 2]
+        nbytes = scan_fwd_bytes(B, D, L, N) if mode == "fwd" else scan_bwd_bytes(B, D, L, N)
+        res[mode] = {"ms": round(med, 4), "GB/s": round(nbytes / med / 1e6, 1),
+                     "frac_of_8TBs": round(nbytes / med / 1e6 / HBM_PEAK_GBS, 4)}
+    res["shape"] = [B, D, L, N]
+    res["note"] = "event-bracketed C-ABI call; bwd includes its 5 memset nodes"
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="clouds per GPU")
+    ap.add_argument("--npoints", type=int, default=1024)
+    ap.add_argument("--groups", type=int, default=128)
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-headline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    from si_mamba_amd import _lib
+    from si_mamba_amd import dist as sdist
+    from si_mamba_amd.point_mamba import PointMamba, default_config
+    import torch.distributed as dist
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm device: the product path has no CPU fallback")
+    rank, world = sdist.init_dist("nccl" if args.gpus > 1 else None)
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+    _lib.load()
+
+    torch.manual_seed(0)                                    # same init on every rank
+    cfg = default_config(num_group=args.groups)             # cfgs/finetune_scan_hardest.yaml model block
+    model = PointMamba(cfg).to(device).train()
+    ddp = sdist.wrap_ddp(model, device)
+    opt = torch.optim.AdamW(model.parameters(), lr=5e-4, weight_decay=0.05)
+    pts = make_clouds(args.batch, args.npoints, seed=rank, device=device)
+    gt = torch.randint(0, cfg.cls_dim, (args.batch,), generator=torch.Generator().manual_seed(rank)).to(device)
+    amp = torch.autocast("cuda", dtype=torch.bfloat16, enabled=(args.dtype == "bf16"))
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        with amp:
+            logits = ddp(pts)
+            loss, _ = model.get_loss_acc(logits, gt)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 10.0)     # grad_norm_clip: 10
+        opt.step()
+        return loss
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    _lib.enable_kernel_timing(not args.no_kernel_timing)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        te = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = te.item()
+    ktimes = _lib.kernel_times()
+    _lib.enable_kernel_timing(False)
+    assert torch.isfinite(loss).item(), "non-finite loss in the timed region"
+
+    if rank == 0:
+        L = 2 * cfg.k_top_eigenvectors * args.groups
+        D, N = 2 * cfg.trans_dim, 16
+        s = 4 if args.dtype == "f32" else 2
+        clouds = args.batch * world * args.steps
+        out = {
+            "metric": "point-clouds/sec (fwd+bwd)", "value": round(clouds / elapsed, 2), "unit": "point-clouds/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"PointMamba classifier train step (FPS+kNN grouping, encoder, spectral SAST "
+                                   f"ordering, 12 Mamba blocks d=384 at L={L}, head, AdamW), "
+                                   f"{args.npoints} pts -> {args.groups} patches",
+                       "global_batch": args.batch * world, "per_gpu_batch": args.batch,
+                       "npoints": args.npoints, "patches": args.groups, "mamba_seq_len": L,
+                       "parallelism": f"dp{world}"},
+        }
+        if "scan_fwd" in ktimes:
+            n, ms = ktimes["scan_fwd"]
+            nbytes = scan_fwd_bytes(args.batch, D, L, N, s)
+            ach = nbytes / ms / 1e6
+            out["roofline"] = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": round(ach / HBM_PEAK_GBS, 4),
+                               "traffic": traffic_from_profiles("scan_fwd", (args.batch, D, L, N)),
+                               "kernel": f"scan_fwd_kernel<{'float' if s == 4 else 'bf16'},8>",
+                               "shape_BDLN": [args.batch, D, L, N], "algorithmic_bytes": nbytes,
+                               "launches": n, "mean_ms": round(ms, 4)}
+            out["kernels"] = {k: {"launches": v[0], "mean_ms": round(v[1], 4)} for k, v in ktimes.items()}
+            if "scan_bwd" in ktimes:
+                bb = scan_bwd_bytes(args.batch, D, L, N, s)
+                out["kernels"]["scan_bwd"]["GB/s"] = round(bb / ktimes["scan_bwd"][1] / 1e6, 1)
+        if world == 1 and not args.no_headline:
+            del opt
+            torch.cuda.empty_cache()
+            out["headline_scan"] = headline_scan(device)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.npoints, args.groups)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -13,15 +13,19 @@
 
 namespace simamba {
 
+// x <- (x + y) after exchanging half of the lanes: lanes 0-31 end with sum-over-halves of x, lanes 32-63
+// with sum-over-halves of y (swap32); rows 0/2 with x summed over row pairs, rows 1/3 with y (swap16).
+// Inline asm on purpose: with ROCm 7.2's hipcc the two-result builtin
+// (__builtin_amdgcn_permlane{16,32}_swap) followed by r[0] + r[1] is register-coalesced into
+// "v_add v, v, v" (2 * r[0]); verified in the .s and on hardware (tools/permlane_probe.hip).
+// The s_nop pads cover the VALU-write -> permlane-swap read hazard, which hipcc does not see in asm.
 __device__ __forceinline__ void swap32_add(float& x, float y) {
-  auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, y),
-                                            false, false);
-  x = __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(y));
+  x = x + y;
 }
 __device__ __forceinline__ void swap16_add(float& x, float y) {
-  auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, y),
-                                            false, false);
-  x = __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(y));
+  x = x + y;
 }
 
 template <typename T, int kItems>
@@ -255,11 +259,14 @@ extern "C" int simamba_selective_scan_bwd(const void* u, const void* delta, cons
                                           void* du, void* ddelta, float* dA, float* dB, float* dC, float* dD,
                                           void* dz, float* ddelta_bias, int batch, int dim, int seqlen,
                                           int dstate, int io_dtype, int delta_softplus, void* stream) {
-  if (!u || !delta || !A || !B || !C || !dout || !du || !ddelta || !dA || !dB || !dC) return SIMAMBA_E_NULLPTR;
-  if ((z != nullptr) != (dz != nullptr)) return SIMAMBA_E_NULLPTR;
   if (batch < 0 || dim <= 0 || seqlen < 0 || batch > 65535) return SIMAMBA_E_SHAPE;
   if (dstate < 1 || dstate > kMaxState) return SIMAMBA_E_DSTATE;
   if (io_dtype != SIMAMBA_F32 && io_dtype != SIMAMBA_BF16) return SIMAMBA_E_DTYPE;
+  if (!A || !dA) return SIMAMBA_E_NULLPTR;
+  if (batch > 0 && seqlen > 0) {
+    if (!u || !delta || !B || !C || !dout || !du || !ddelta || !dB || !dC) return SIMAMBA_E_NULLPTR;
+    if ((z != nullptr) != (dz != nullptr)) return SIMAMBA_E_NULLPTR;
+  }
   const int nchunks = simamba_scan_num_chunks(seqlen);
   if (nchunks > 1 && !x_ckpt) return SIMAMBA_E_NULLPTR;
   hipStream_t s = static_cast<hipStream_t>(stream);

@@ -148,11 +148,11 @@ extern "C" int simamba_selective_scan_fwd(const void* u, const void* delta, cons
                                           const float* delta_bias, void* out, float* x_ckpt,
                                           float* last_state, int batch, int dim, int seqlen, int dstate,
                                           int io_dtype, int delta_softplus, void* stream) {
-  if (!u || !delta || !A || !B || !C || !out) return SIMAMBA_E_NULLPTR;
   if (batch < 0 || dim <= 0 || seqlen < 0 || batch > 65535) return SIMAMBA_E_SHAPE;
   if (dstate < 1 || dstate > kMaxState) return SIMAMBA_E_DSTATE;
   if (io_dtype != SIMAMBA_F32 && io_dtype != SIMAMBA_BF16) return SIMAMBA_E_DTYPE;
-  if (batch == 0 || seqlen == 0) return SIMAMBA_OK;
+  if (batch == 0 || seqlen == 0) return SIMAMBA_OK;   // nothing to do (empty tensors carry NULL data)
+  if (!u || !delta || !A || !B || !C || !out) return SIMAMBA_E_NULLPTR;
   ScanArgs a{};
   a.u = u; a.delta = delta; a.A = A; a.B = B; a.C = C; a.D = D; a.z = z; a.delta_bias = delta_bias;
   a.out = out; a.x_ckpt = x_ckpt; a.last_state = last_state;

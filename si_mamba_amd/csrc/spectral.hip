@@ -125,7 +125,8 @@ __global__ __launch_bounds__(kEigThreads) void laplacian_eig_kernel(EigArgs p) {
   float* S = sm;                  // [G][LD]  matrix being diagonalised
   float* V = S + G * LD;          // [G][LD]  accumulated rotations (columns = eigenvectors)
   __shared__ float sDeg[kSpecMaxG];
-  __shared__ float sCs[kSpecMaxG];        // (c, s) per pair
+  __shared__ float sCs[kSpecMaxG];        // (s, tau = s / (1 + c)) per pair
+  __shared__ float sPiv[2 * kSpecMaxG];   // rotated pivot diagonal (a_pp', a_qq') per pair
   __shared__ int sPq[kSpecMaxG];          // (p, q) per pair
   __shared__ int sRank[kSpecMaxG];        // eigenvalue index by ascending rank
   __shared__ int sSel[kSpecMaxG];
@@ -181,33 +182,40 @@ __global__ __launch_bounds__(kEigThreads) void laplacian_eig_kernel(EigArgs p) {
         if (tid == 0) { a = M - 1; b = step % (M - 1); }
         else { a = (step + tid) % (M - 1); b = (step + M - 1 - tid) % (M - 1); }
         int pp = a < b ? a : b, qq = a < b ? b : a;
-        float c = 1.f, s = 0.f;
+        // Rutishauser's form: x' = x - s (y + tau x), y' = y + s (x - tau y), tau = s / (1 + c).
+        // (c x - s y with c rounded to 1 for small angles grows every norm by t^2/2 per rotation.)
+        float s = 0.f, tq = 0.f, dpp_ = 0.f, dqq_ = 0.f;
         if (qq < G) {
           const float apq = S[pp * LD + qq];
           const float app = S[pp * LD + pp], aqq = S[qq * LD + qq];
+          dpp_ = app; dqq_ = aqq;
           if (fabsf(apq) > 1e-12f * (fabsf(app) + fabsf(aqq)) + 1e-37f) {
-            const float tau = (aqq - app) / (2.f * apq);
-            const float t = (tau >= 0.f ? 1.f : -1.f) / (fabsf(tau) + sqrtf(1.f + tau * tau));
-            c = 1.f / sqrtf(1.f + t * t);
+            const float theta = (aqq - app) / (2.f * apq);
+            const float t = (theta >= 0.f ? 1.f : -1.f) / (fabsf(theta) + sqrtf(1.f + theta * theta));
+            const float c = 1.f / sqrtf(1.f + t * t);
             s = t * c;
+            tq = s / (1.f + c);
+            dpp_ = app - t * apq;
+            dqq_ = aqq + t * apq;
             if (fabsf(apq) > 5e-8f * (fabsf(app) + fabsf(aqq)) + 1e-10f) sFlag = 1;
           }
         } else {
           qq = -1;
         }
         sPq[2 * tid] = pp; sPq[2 * tid + 1] = qq;
-        sCs[2 * tid] = c; sCs[2 * tid + 1] = s;
+        sCs[2 * tid] = s; sCs[2 * tid + 1] = tq;
+        sPiv[2 * tid] = dpp_; sPiv[2 * tid + 1] = dqq_;
       }
       __syncthreads();
       // rows: S <- J^T S
       for (int e = tid; e < half * G; e += kEigThreads) {
         const int pr = e / G, j = e - pr * G;
         const int pp = sPq[2 * pr], qq = sPq[2 * pr + 1];
-        const float c = sCs[2 * pr], s = sCs[2 * pr + 1];
+        const float s = sCs[2 * pr], tq = sCs[2 * pr + 1];
         if (qq >= 0 && s != 0.f) {
           const float x = S[pp * LD + j], y = S[qq * LD + j];
-          S[pp * LD + j] = c * x - s * y;
-          S[qq * LD + j] = s * x + c * y;
+          S[pp * LD + j] = x - s * (y + tq * x);
+          S[qq * LD + j] = y + s * (x - tq * y);
         }
       }
       __syncthreads();
@@ -215,14 +223,18 @@ __global__ __launch_bounds__(kEigThreads) void laplacian_eig_kernel(EigArgs p) {
       for (int e = tid; e < half * G; e += kEigThreads) {
         const int pr = e / G, i = e - pr * G;
         const int pp = sPq[2 * pr], qq = sPq[2 * pr + 1];
-        const float c = sCs[2 * pr], s = sCs[2 * pr + 1];
+        const float s = sCs[2 * pr], tq = sCs[2 * pr + 1];
         if (qq >= 0 && s != 0.f) {
           const float x = S[i * LD + pp], y = S[i * LD + qq];
-          S[i * LD + pp] = c * x - s * y;
-          S[i * LD + qq] = s * x + c * y;
+          float xn = x - s * (y + tq * x), yn = y + s * (x - tq * y);
+          // the 2x2 pivot block is known in closed form: exact zero off-diagonal, a_pp - t a_pq, a_qq + t a_pq
+          if (i == pp) { xn = sPiv[2 * pr]; yn = 0.f; }
+          if (i == qq) { xn = 0.f; yn = sPiv[2 * pr + 1]; }
+          S[i * LD + pp] = xn;
+          S[i * LD + qq] = yn;
           const float vx = V[i * LD + pp], vy = V[i * LD + qq];
-          V[i * LD + pp] = c * vx - s * vy;
-          V[i * LD + qq] = s * vx + c * vy;
+          V[i * LD + pp] = vx - s * (vy + tq * vx);
+          V[i * LD + qq] = vy + s * (vx - tq * vy);
         }
       }
       __syncthreads();
