@@ -29,14 +29,14 @@ __device__ __forceinline__ void swap16_add(float& x, float y) {
 }
 
 template <typename T, int kItems>
-__global__ __launch_bounds__(kScanThreads) void scan_bwd_kernel(ScanArgs p) {
+__global__ __launch_bounds__(kScanThreads, 2) void scan_bwd_kernel(ScanArgs p) {
   constexpr int LC = 16 * kItems;
   constexpr int LDP = LC + 4;
   constexpr int KH = kItems / 2;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sB = smem;                          // [kMaxState][LDP]
   float* sC = sB + kMaxState * LDP;          // [kMaxState][LDP]
-  float* sAcc = sC + kMaxState * LDP;        // [2][kMaxState][LC]   dB / dC of this chunk
+  float* sAcc = sC + kMaxState * LDP;        // [2][kMaxState][LC]   dB / dC of this chunk (cross-wave sum)
   float* sG = sAcc + 2 * kMaxState * LC;     // [16*passes][kMaxState] adjoint state entering from the right
   float* sDf = sG + kRowsPerPass * p.passes * kMaxState;  // [16*passes] delta of the next chunk's first step
 
@@ -44,6 +44,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_bwd_kernel(ScanArgs p) {
   const int tile_base = blockIdx.x * (kRowsPerPass * p.passes);
   const int lane16 = threadIdx.x & 15;
   const int rowslot = threadIdx.x >> 4;
+  const int wave = threadIdx.x >> 6;
   const int sub = rowslot & 3;               // channel row inside the wave
   const int L = p.seqlen, D = p.dim, N = p.dstate;
   const T* __restrict__ ug = static_cast<const T*>(p.u);
@@ -58,9 +59,16 @@ __global__ __launch_bounds__(kScanThreads) void scan_bwd_kernel(ScanArgs p) {
   for (int c = p.nchunks - 1; c >= 0; --c) {
     __syncthreads();
     stage_bc<T, LC>(static_cast<const T*>(p.B), static_cast<const T*>(p.C), sB, sC, b, N, L, c);
-    for (int i = threadIdx.x; i < 2 * kMaxState * LC; i += kScanThreads) sAcc[i] = 0.f;
     __syncthreads();
     const bool last_chunk = (c == p.nchunks - 1);
+
+    // dB / dC partial sums of this wave over its passes: after the transposing reduction, row `sub` of the
+    // wave owns tensor (sub >> 1) and items [(sub & 1) * KH, +KH) of every state n.
+    float acc[kMaxState][KH];
+#pragma unroll
+    for (int n = 0; n < kMaxState; ++n)
+#pragma unroll
+      for (int i = 0; i < KH; ++i) acc[n][i] = 0.f;
 
     for (int r = 0; r < p.passes; ++r) {
       const int slot = r * kRowsPerPass + rowslot;
@@ -72,12 +80,14 @@ __global__ __launch_bounds__(kScanThreads) void scan_bwd_kernel(ScanArgs p) {
       nvalid = nvalid < 0 ? 0 : (nvalid > kItems ? kItems : nvalid);
       const size_t off = (static_cast<size_t>(b) * D + dc) * L + t0;
 
-      float u[kItems], dl[kItems], sg[kItems], zz[kItems], dy[kItems], go[kItems];
+      float u[kItems], dl[kItems], zz[kItems], dy[kItems], go[kItems];
       float ypre[kItems], dxs[kItems], dda[kItems], du[kItems];
       load_items<T, kItems>(ug + off, nvalid, vec, u);
       load_items<T, kItems>(dg + off, nvalid, vec, dl);
       load_items<T, kItems>(gg + off, nvalid, vec, go);
       if (zg) load_items<T, kItems>(zg + off, nvalid, vec, zz);
+      float A2[kMaxState];
+      load_A_row(p.A + static_cast<size_t>(dc) * N, N, A2);
 
       const float bias = p.delta_bias ? p.delta_bias[dc] : 0.f;
       const float Dd = p.D ? p.D[dc] : 0.f;
@@ -85,15 +95,10 @@ __global__ __launch_bounds__(kScanThreads) void scan_bwd_kernel(ScanArgs p) {
 #pragma unroll
       for (int i = 0; i < kItems; ++i) {
         float x = dl[i] + bias;
-        float s = 1.f;
-        if (p.softplus) {
-          s = (x > 20.f) ? 1.f : sigmoid_f(x);
-          x = softplus_f(x);
-        }
+        x = p.softplus ? softplus_f(x) : x;
         const bool ok = i < nvalid;
         x = ok ? x : 0.f;
         dl[i] = x;
-        sg[i] = s;
         sumd += x;
         du[i] = x * u[i];
         go[i] = (ok && dvalid) ? go[i] : 0.f;
@@ -103,85 +108,85 @@ __global__ __launch_bounds__(kScanThreads) void scan_bwd_kernel(ScanArgs p) {
         dda[i] = 0.f;
       }
       // delta of the step right after this lane's last one (next lane, or next chunk for lane 15)
-      const float dnext_chunk = last_chunk ? 0.f : sDf[slot];
-      const float dnext = dpp<DPP_ROW_SHL + 1>(dnext_chunk, dl[0]);
-
-      const float* __restrict__ Arow = p.A + static_cast<size_t>(dc) * N;
+      const float dnext = row_next(dl[0], last_chunk ? 0.f : sDf[slot]);
       const float* __restrict__ ck =
           (c > 0) ? p.x_ckpt + ((static_cast<size_t>(b) * D + dc) * p.nchunks + (c - 1)) * N : nullptr;
       float dAlane = 0.f;   // lane n of the row ends up holding dA[d][n] of this chunk
 
-      for (int n = 0; n < N; ++n) {
-        const float A2 = Arow[n] * kLog2e;
-        const float* bp = sB + n * LDP + lane16 * kItems;
-        const float* cp = sC + n * LDP + lane16 * kItems;
-        float a[kItems], bw[kItems], cc[kItems], hp[kItems];
 #pragma unroll
-        for (int i = 0; i < kItems; i += 4) {
-          float4 vb = *reinterpret_cast<const float4*>(bp + i);
-          float4 vc = *reinterpret_cast<const float4*>(cp + i);
-          bw[i] = vb.x; bw[i + 1] = vb.y; bw[i + 2] = vb.z; bw[i + 3] = vb.w;
-          cc[i] = vc.x; cc[i + 1] = vc.y; cc[i + 2] = vc.z; cc[i + 3] = vc.w;
+      for (int n = 0; n < kMaxState; ++n) {
+        if (n < N) {
+          const float A2n = A2[n];
+          const float* bp = sB + n * LDP + lane16 * kItems;
+          const float* cp = sC + n * LDP + lane16 * kItems;
+          float a[kItems], bw[kItems], cc[kItems], hp[kItems];
+#pragma unroll
+          for (int i = 0; i < kItems; i += 4) {
+            float4 vb = *reinterpret_cast<const float4*>(bp + i);
+            float4 vc = *reinterpret_cast<const float4*>(cp + i);
+            bw[i] = vb.x; bw[i + 1] = vb.y; bw[i + 2] = vb.z; bw[i + 3] = vb.w;
+            cc[i] = vc.x; cc[i + 1] = vc.y; cc[i + 2] = vc.z; cc[i + 3] = vc.w;
+          }
+          // ---- forward re-scan: h_t -----------------------------------------------------
+          float S = 0.f;
+#pragma unroll
+          for (int i = 0; i < kItems; ++i) {
+            a[i] = fast_exp2(dl[i] * A2n);
+            S = fmaf(a[i], S, du[i] * bw[i]);
+          }
+          float P = fast_exp2(A2n * sumd);
+          row_scan_inclusive(P, S);
+          float h = row_prev(S, 0.f);
+          if (ck) h = fmaf(row_prev(P, 1.f), ck[n], h);
+          float red[2 * kItems];   // [0,K): dB terms, [K,2K): dC terms
+#pragma unroll
+          for (int i = 0; i < kItems; ++i) {
+            hp[i] = h;
+            h = fmaf(a[i], h, du[i] * bw[i]);
+            ypre[i] = fmaf(cc[i], h, ypre[i]);
+            red[kItems + i] = dy[i] * h;
+            cc[i] = cc[i] * dy[i];          // c_t = C_t * dy_t, source term of the adjoint scan
+          }
+          // ---- adjoint scan, right to left: g_t = c_t + a_{t+1} g_{t+1} -----------------
+          const float anext = fast_exp2(dnext * A2n);
+          float G = 0.f;
+#pragma unroll
+          for (int i = kItems - 1; i >= 0; --i) {
+            const float al = (i == kItems - 1) ? anext : a[i + 1];
+            G = fmaf(al, G, cc[i]);
+          }
+          float Q = fast_exp2(A2n * (sumd - dl[0] + dnext));
+          row_scan_inclusive_rev(Q, G);
+          float g = row_next(G, 0.f);
+          if (!last_chunk) {
+            const float gcar = sG[slot * kMaxState + n];
+            g = fmaf(row_next(Q, 1.f), gcar, g);
+            if (c > 0 && lane16 == 0) sG[slot * kMaxState + n] = fmaf(Q, gcar, G);
+          } else if (c > 0 && lane16 == 0) {
+            sG[slot * kMaxState + n] = G;
+          }
+          float dAacc = 0.f;
+#pragma unroll
+          for (int i = kItems - 1; i >= 0; --i) {
+            const float al = (i == kItems - 1) ? anext : a[i + 1];
+            g = fmaf(al, g, cc[i]);
+            red[i] = g * du[i];
+            dxs[i] = fmaf(g, bw[i], dxs[i]);
+            const float q = g * a[i] * hp[i];
+            dda[i] = fmaf(A2n, q, dda[i]);
+            dAacc = fmaf(dl[i], q, dAacc);
+          }
+          dAacc = row_allreduce_sum(dAacc);
+          dAlane = (lane16 == n) ? dAacc : dAlane;
+          // ---- dB / dC: transposing reduction over the wave's 4 channel rows ---------------
+#pragma unroll
+          for (int i = 0; i < kItems; ++i) swap32_add(red[i], red[kItems + i]);
+#pragma unroll
+          for (int i = 0; i < KH; ++i) {
+            swap16_add(red[i], red[KH + i]);
+            acc[n][i] += red[i];
+          }
         }
-        // ---- forward re-scan: h_t -------------------------------------------------------
-        float S = 0.f;
-#pragma unroll
-        for (int i = 0; i < kItems; ++i) {
-          a[i] = fast_exp2(dl[i] * A2);
-          S = fmaf(a[i], S, du[i] * bw[i]);
-        }
-        float P = fast_exp2(A2 * sumd);
-        row_scan_inclusive(P, S);
-        const float Pex = dpp<DPP_ROW_SHR + 1>(1.f, P);
-        const float Sex = dpp<DPP_ROW_SHR + 1>(0.f, S);
-        const float hc = ck ? ck[n] : 0.f;
-        float h = fmaf(Pex, hc, Sex);
-        float red[2 * kItems];   // [0,K): dB terms, [K,2K): dC terms
-#pragma unroll
-        for (int i = 0; i < kItems; ++i) {
-          hp[i] = h;
-          h = fmaf(a[i], h, du[i] * bw[i]);
-          ypre[i] = fmaf(cc[i], h, ypre[i]);
-          red[kItems + i] = dy[i] * h;
-          cc[i] = cc[i] * dy[i];          // c_t = C_t * dy_t, source term of the adjoint scan
-        }
-        // ---- adjoint scan, right to left: g_t = c_t + a_{t+1} g_{t+1} -------------------
-        const float anext = fast_exp2(dnext * A2);
-        float G = 0.f;
-#pragma unroll
-        for (int i = kItems - 1; i >= 0; --i) {
-          const float al = (i == kItems - 1) ? anext : a[i + 1];
-          G = fmaf(al, G, cc[i]);
-        }
-        float Q = fast_exp2(A2 * (sumd - dl[0] + dnext));
-        row_scan_inclusive_rev(Q, G);
-        const float Qex = dpp<DPP_ROW_SHL + 1>(1.f, Q);
-        const float Gex = dpp<DPP_ROW_SHL + 1>(0.f, G);
-        const float gcar = last_chunk ? 0.f : sG[slot * kMaxState + n];
-        float g = fmaf(Qex, gcar, Gex);
-        if (c > 0 && lane16 == 0) sG[slot * kMaxState + n] = fmaf(Q, gcar, G);
-        float dAacc = 0.f;
-#pragma unroll
-        for (int i = kItems - 1; i >= 0; --i) {
-          const float al = (i == kItems - 1) ? anext : a[i + 1];
-          g = fmaf(al, g, cc[i]);
-          red[i] = g * du[i];
-          dxs[i] = fmaf(g, bw[i], dxs[i]);
-          const float q = g * a[i] * hp[i];
-          dda[i] = fmaf(A2, q, dda[i]);
-          dAacc = fmaf(dl[i], q, dAacc);
-        }
-        dAacc = row_allreduce_sum(dAacc);
-        dAlane = (lane16 == n) ? dAacc : dAlane;
-        // ---- dB / dC: reduce over the wave's 4 channel rows, then into the LDS tile ------
-#pragma unroll
-        for (int i = 0; i < kItems; ++i) swap32_add(red[i], red[kItems + i]);
-#pragma unroll
-        for (int i = 0; i < KH; ++i) swap16_add(red[i], red[KH + i]);
-        // row `sub` now holds: tensor = sub>>1 (0 dB, 1 dC), items [ (sub&1)*KH, +KH )
-        float* accp = sAcc + ((sub >> 1) * kMaxState + n) * LC + lane16 * kItems + (sub & 1) * KH;
-#pragma unroll
-        for (int i = 0; i < KH; ++i) atomicAdd(accp + i, red[i]);
       }
 
       // ---- per-timestep gradients ---------------------------------------------------------
@@ -189,7 +194,9 @@ __global__ __launch_bounds__(kScanThreads) void scan_bwd_kernel(ScanArgs p) {
       float sD = 0.f, sBias = 0.f;
 #pragma unroll
       for (int i = 0; i < kItems; ++i) {
-        const float gd = fmaf(u[i], dxs[i], kLn2 * dda[i]) * sg[i];
+        // d softplus(x)/dx = sigmoid(x) = 1 - exp(-softplus(x)); padded steps carry no gradient
+        const float sgm = p.softplus ? (1.f - fast_exp2(-dl[i] * kLog2e)) : 1.f;
+        const float gd = fmaf(u[i], dxs[i], kLn2 * dda[i]) * sgm;
         ddl[i] = gd;
         sBias += gd;
         sD = fmaf(dy[i], u[i], sD);
@@ -215,8 +222,23 @@ __global__ __launch_bounds__(kScanThreads) void scan_bwd_kernel(ScanArgs p) {
       if (c > 0 && lane16 == 0) sDf[slot] = dl[0];
     }
 
-    __syncthreads();
-    // flush the chunk's dB / dC tile
+    // ---- cross-wave sum of the dB / dC partials through one LDS tile, then one atomic flush -----
+    float* accp = sAcc + (sub >> 1) * kMaxState * LC + lane16 * kItems + (sub & 1) * KH;
+    for (int w = 0; w < kScanThreads / 64; ++w) {
+      if (wave == w) {
+#pragma unroll
+        for (int n = 0; n < kMaxState; ++n) {
+          if (n < N) {
+#pragma unroll
+            for (int i = 0; i < KH; ++i) {
+              const float prev = (w == 0) ? 0.f : accp[n * LC + i];
+              accp[n * LC + i] = prev + acc[n][i];
+            }
+          }
+        }
+      }
+      __syncthreads();
+    }
     for (int i = threadIdx.x; i < 2 * N * LC; i += kScanThreads) {
       const int tensor = i / (N * LC);
       const int rem = i - tensor * (N * LC);
@@ -292,8 +314,13 @@ extern "C" int simamba_selective_scan_bwd(const void* u, const void* delta, cons
   const size_t esz = io_dtype == SIMAMBA_F32 ? 4 : 2;
   a.vec = ((seqlen * esz) % 16 == 0) && aligned16b(u) && aligned16b(delta) && aligned16b(dout) &&
           aligned16b(du) && aligned16b(ddelta) && (!z || (aligned16b(z) && aligned16b(dz)));
-  int passes = 4;
-  while (passes > 1 && static_cast<long long>(batch) * ((dim + 16 * passes - 1) / (16 * passes)) < 768) passes >>= 1;
+  // channels per workgroup (16 * passes): the more, the fewer dB/dC atomics reach HBM; but keep >= 4
+  // workgroups per CU so that the two resident per CU always have successors
+  static const int kCand[] = {12, 8, 6, 4, 3, 2, 1};
+  int passes = 1;
+  for (int cand : kCand) {
+    if (static_cast<long long>(batch) * ((dim + 16 * cand - 1) / (16 * cand)) >= 1024) { passes = cand; break; }
+  }
   a.passes = passes;
   return io_dtype == SIMAMBA_F32 ? launch_bwd<float>(a, s) : launch_bwd<bf16_t>(a, s);
 }

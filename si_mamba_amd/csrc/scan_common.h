@@ -48,37 +48,64 @@ struct ScanArgs {
   int softplus;
 };
 
-// inclusive scan over the 16 lanes of a row of the affine map (P,S) : h -> P*h + S,
-// composed left to right (lane 0 first).
+// Inclusive scan over the 16 lanes of a row of the affine map (P,S) : h -> P*h + S, composed left to
+// right (lane 0 first).  Each step is two fused DPP instructions: lanes whose source lane falls outside
+// the row are simply not written (bound_ctrl:0), which is the identity of the composition -- no v_mov of
+// identity values, no select.  Inline asm because hipcc does not fold update_dpp into the consumer here;
+// the s_nop pads are the "VALU write -> DPP read of the same VGPR: 2 wait states" hazard.
 __device__ __forceinline__ void row_scan_inclusive(float& P, float& S) {
-#define SIMAMBA_SCAN_STEP(N)                                   \
-  {                                                            \
-    float Pp = dpp<DPP_ROW_SHR + N>(1.f, P);                   \
-    float Sp = dpp<DPP_ROW_SHR + N>(0.f, S);                   \
-    S = fmaf(P, Sp, S);                                        \
-    P = P * Pp;                                                \
-  }
-  SIMAMBA_SCAN_STEP(1)
-  SIMAMBA_SCAN_STEP(2)
-  SIMAMBA_SCAN_STEP(4)
-  SIMAMBA_SCAN_STEP(8)
-#undef SIMAMBA_SCAN_STEP
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_fmac_f32_dpp %0, %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+      "v_mul_f32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 0\n\t"
+      "v_fmac_f32_dpp %0, %0, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+      "v_mul_f32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 0\n\t"
+      "v_fmac_f32_dpp %0, %0, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+      "v_mul_f32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 0\n\t"
+      "v_fmac_f32_dpp %0, %0, %1 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_mul_f32_dpp %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1"
+      : "+v"(S), "+v"(P));
 }
 
 // same, composed right to left (lane 15 first): g_out = Q * g_in + G with g flowing to lower lanes
 __device__ __forceinline__ void row_scan_inclusive_rev(float& Q, float& G) {
-#define SIMAMBA_SCAN_STEP(N)                                   \
-  {                                                            \
-    float Qn = dpp<DPP_ROW_SHL + N>(1.f, Q);                   \
-    float Gn = dpp<DPP_ROW_SHL + N>(0.f, G);                   \
-    G = fmaf(Q, Gn, G);                                        \
-    Q = Q * Qn;                                                \
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_fmac_f32_dpp %0, %0, %1 row_shl:1 row_mask:0xf bank_mask:0xf\n\t"
+      "v_mul_f32_dpp %1, %1, %1 row_shl:1 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 0\n\t"
+      "v_fmac_f32_dpp %0, %0, %1 row_shl:2 row_mask:0xf bank_mask:0xf\n\t"
+      "v_mul_f32_dpp %1, %1, %1 row_shl:2 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 0\n\t"
+      "v_fmac_f32_dpp %0, %0, %1 row_shl:4 row_mask:0xf bank_mask:0xf\n\t"
+      "v_mul_f32_dpp %1, %1, %1 row_shl:4 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 0\n\t"
+      "v_fmac_f32_dpp %0, %0, %1 row_shl:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_mul_f32_dpp %1, %1, %1 row_shl:8 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1"
+      : "+v"(G), "+v"(Q));
+}
+
+// value of the previous (SHR) / next (SHL) lane of the row; `edge` where there is none
+__device__ __forceinline__ float row_prev(float v, float edge) { return dpp<DPP_ROW_SHR + 1>(edge, v); }
+__device__ __forceinline__ float row_next(float v, float edge) { return dpp<DPP_ROW_SHL + 1>(edge, v); }
+
+// the 16 per-state coefficients A[d][0..N) of a row, pre-scaled by log2(e), as registers
+__device__ __forceinline__ void load_A_row(const float* __restrict__ Arow, int N, float (&A2)[kMaxState]) {
+  if (N == kMaxState) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 v = *reinterpret_cast<const float4*>(Arow + 4 * q);
+      A2[4 * q] = v.x * kLog2e; A2[4 * q + 1] = v.y * kLog2e; A2[4 * q + 2] = v.z * kLog2e; A2[4 * q + 3] = v.w * kLog2e;
+    }
+  } else {
+#pragma unroll
+    for (int n = 0; n < kMaxState; ++n) A2[n] = (n < N) ? Arow[n] * kLog2e : 0.f;
   }
-  SIMAMBA_SCAN_STEP(1)
-  SIMAMBA_SCAN_STEP(2)
-  SIMAMBA_SCAN_STEP(4)
-  SIMAMBA_SCAN_STEP(8)
-#undef SIMAMBA_SCAN_STEP
 }
 
 // stage the chunk's B and C tiles (dstate x LC) of one batch sample into LDS, zero padded

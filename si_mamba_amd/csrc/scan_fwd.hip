@@ -62,37 +62,42 @@ __global__ __launch_bounds__(kScanThreads) void scan_fwd_kernel(ScanArgs p) {
         y[i] = Dd * u[i];
       }
 
-      const float* __restrict__ Arow = p.A + static_cast<size_t>(dc) * N;
-      for (int n = 0; n < N; ++n) {
-        const float A2 = Arow[n] * kLog2e;
-        const float* bp = sB + n * LDP + lane16 * kItems;
-        const float* cp = sC + n * LDP + lane16 * kItems;
-        float a[kItems], bb[kItems], cc[kItems];
+      float A2[kMaxState];
+      load_A_row(p.A + static_cast<size_t>(dc) * N, N, A2);
 #pragma unroll
-        for (int i = 0; i < kItems; i += 4) {
-          float4 vb = *reinterpret_cast<const float4*>(bp + i);
-          float4 vc = *reinterpret_cast<const float4*>(cp + i);
-          bb[i] = vb.x; bb[i + 1] = vb.y; bb[i + 2] = vb.z; bb[i + 3] = vb.w;
-          cc[i] = vc.x; cc[i + 1] = vc.y; cc[i + 2] = vc.z; cc[i + 3] = vc.w;
-        }
-        float S = 0.f;
+      for (int n = 0; n < kMaxState; ++n) {
+        if (n < N) {
+          const float A2n = A2[n];
+          const float* bp = sB + n * LDP + lane16 * kItems;
+          const float* cp = sC + n * LDP + lane16 * kItems;
+          float a[kItems], bb[kItems], cc[kItems];
 #pragma unroll
-        for (int i = 0; i < kItems; ++i) {
-          a[i] = fast_exp2(dl[i] * A2);
-          bb[i] = du[i] * bb[i];
-          S = fmaf(a[i], S, bb[i]);
-        }
-        float P = fast_exp2(A2 * sumd);
-        row_scan_inclusive(P, S);
-        const float Pex = dpp<DPP_ROW_SHR + 1>(1.f, P);
-        const float Sex = dpp<DPP_ROW_SHR + 1>(0.f, S);
-        const float carry = (c > 0) ? sCarry[slot * kMaxState + n] : 0.f;
-        float h = fmaf(Pex, carry, Sex);
-        if (keep_state && lane16 == 15) sCarry[slot * kMaxState + n] = fmaf(P, carry, S);
+          for (int i = 0; i < kItems; i += 4) {
+            float4 vb = *reinterpret_cast<const float4*>(bp + i);
+            float4 vc = *reinterpret_cast<const float4*>(cp + i);
+            bb[i] = vb.x; bb[i + 1] = vb.y; bb[i + 2] = vb.z; bb[i + 3] = vb.w;
+            cc[i] = vc.x; cc[i + 1] = vc.y; cc[i + 2] = vc.z; cc[i + 3] = vc.w;
+          }
+          float S = 0.f;
 #pragma unroll
-        for (int i = 0; i < kItems; ++i) {
-          h = fmaf(a[i], h, bb[i]);
-          y[i] = fmaf(cc[i], h, y[i]);
+          for (int i = 0; i < kItems; ++i) {
+            a[i] = fast_exp2(dl[i] * A2n);
+            bb[i] = du[i] * bb[i];
+            S = fmaf(a[i], S, bb[i]);
+          }
+          float P = fast_exp2(A2n * sumd);
+          row_scan_inclusive(P, S);
+          float h = row_prev(S, 0.f);
+          if (c > 0 || keep_state) {
+            const float carry = (c > 0) ? sCarry[slot * kMaxState + n] : 0.f;
+            if (c > 0) h = fmaf(row_prev(P, 1.f), carry, h);
+            if (keep_state && lane16 == 15) sCarry[slot * kMaxState + n] = fmaf(P, carry, S);
+          }
+#pragma unroll
+          for (int i = 0; i < kItems; ++i) {
+            h = fmaf(a[i], h, bb[i]);
+            y[i] = fmaf(cc[i], h, y[i]);
+          }
         }
       }
 
