@@ -26,7 +26,11 @@
  *     void*); no device-wide synchronisation, no default-stream use, no hipSetDevice.
  *   - Return 0 on success; <0 = argument error detected before any launch (SIMAMBA_E_*);
  *     >0 = hipError_t reported by the runtime for the launch.  simamba_strerror() decodes both.
- *   - Tensors are contiguous in the layouts stated per function.
+ *   - Tensors are contiguous in the layouts stated per function, except where a stride argument
+ *     (in ELEMENTS) is given: z / dz / conv x / conv dx may be batch-strided views (e.g. halves of
+ *     the mixer's (batch, 2*dim, seqlen) in_proj output), and B, C may be read through arbitrary
+ *     (batch, state, time) strides (e.g. straight out of the (batch, seqlen, R+2N) x_proj output).
+ *     A stride of 0 means "contiguous default".
  *   - io_dtype: SIMAMBA_F32 or SIMAMBA_BF16 for activation-sized tensors; all state,
  *     accumulation and parameter gradients are fp32.
  */
@@ -39,7 +43,7 @@
 extern "C" {
 #endif
 
-#define SIMAMBA_ABI_VERSION 1
+#define SIMAMBA_ABI_VERSION 2
 
 #define SIMAMBA_F32  0
 #define SIMAMBA_BF16 1
@@ -65,7 +69,9 @@ int         simamba_scan_num_chunks(int seqlen);
  * Selective scan forward.
  *   u, delta, z, out : (batch, dim, seqlen)  io_dtype      z may be NULL (no gating)
  *   A                : (dim, dstate) fp32                   (already -exp(A_log))
- *   B, C             : (batch, dstate, seqlen) io_dtype
+ *   B, C             : (batch, dstate, seqlen) io_dtype, element (b,n,t) at b*bc_bstride + n*bc_nstride
+ *                      + t*bc_tstride (all three 0 => contiguous (batch, dstate, seqlen))
+ *   z_bstride        : elements between consecutive batch samples of z (0 => dim*seqlen)
  *   D, delta_bias    : (dim) fp32, may be NULL
  *   x_ckpt           : (batch, dim, nchunks, dstate) fp32 or NULL.  State at the END of every
  *                      chunk; required by the backward when nchunks > 1.
@@ -76,14 +82,17 @@ int simamba_selective_scan_fwd(const void* u, const void* delta, const float* A,
                                const void* B, const void* C, const float* D, const void* z,
                                const float* delta_bias, void* out, float* x_ckpt,
                                float* last_state, int batch, int dim, int seqlen, int dstate,
-                               int io_dtype, int delta_softplus, void* stream);
+                               int io_dtype, int delta_softplus, long long z_bstride,
+                               long long bc_bstride, long long bc_nstride, long long bc_tstride,
+                               void* stream);
 
 /*
  * Selective scan backward.  Inputs as forward (+ dout, x_ckpt from the forward when
  * nchunks > 1).  du, ddelta, dz : io_dtype (dz NULL iff z NULL).
  * dA (dim,dstate), dB, dC (batch,dstate,seqlen), dD, ddelta_bias (dim): fp32; the library
  * zeroes them on `stream` and then accumulates (float atomics: last-bit run-to-run jitter).
- * dD / ddelta_bias may be NULL when D / delta_bias are NULL.
+ * dD / ddelta_bias may be NULL when D / delta_bias are NULL.  dB / dC are always contiguous
+ * (batch, dstate, seqlen); z, dz and B, C take strides as in the forward.
  */
 int simamba_selective_scan_bwd(const void* u, const void* delta, const float* A,
                                const void* B, const void* C, const float* D, const void* z,
@@ -91,21 +100,24 @@ int simamba_selective_scan_bwd(const void* u, const void* delta, const float* A,
                                void* du, void* ddelta, float* dA, float* dB, float* dC,
                                float* dD, void* dz, float* ddelta_bias,
                                int batch, int dim, int seqlen, int dstate,
-                               int io_dtype, int delta_softplus, void* stream);
+                               int io_dtype, int delta_softplus, long long z_bstride,
+                               long long dz_bstride, long long bc_bstride, long long bc_nstride,
+                               long long bc_tstride, void* stream);
 
 /*
  * Causal depthwise conv1d (+ optional SiLU).
  *   x, out, dout, dx : (batch, dim, seqlen) io_dtype
  *   w : (dim, width) fp32; bias : (dim) fp32 or NULL; dw, dbias fp32, zeroed then accumulated.
  *   out[b,d,t] = act(bias[d] + sum_k w[d,k] * x[b,d,t-(width-1)+k])
+ *   x_bstride / dx_bstride: elements between batch samples of x / dx (0 => dim*seqlen).
  */
 int simamba_causal_conv1d_fwd(const void* x, const float* w, const float* bias, void* out,
                               int batch, int dim, int seqlen, int width, int silu,
-                              int io_dtype, void* stream);
+                              int io_dtype, long long x_bstride, void* stream);
 int simamba_causal_conv1d_bwd(const void* x, const float* w, const float* bias,
                               const void* dout, void* dx, float* dw, float* dbias,
                               int batch, int dim, int seqlen, int width, int silu,
-                              int io_dtype, void* stream);
+                              int io_dtype, long long x_bstride, long long dx_bstride, void* stream);
 
 /* ---- spectral ordering ---------------------------------------------------------------- */
 #define SIMAMBA_SPEC_SYMMETRIC   0x01u  /* also write A[j,i] for every kNN edge (i,j)          */

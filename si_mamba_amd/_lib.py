@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_size_t, c_uint, c_void_p
+from ctypes import c_char_p, c_float, c_int, c_longlong, c_size_t, c_uint, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsimamba_hip.so")
@@ -24,18 +24,22 @@ SPEC_SIGMA_MEAN = 0x20
 
 # name -> (restype, argtypes); mirrors include/simamba.h one to one
 _P = c_void_p
+_LL = c_longlong
+ABI_VERSION = 2
 SIGNATURES = {
     "simamba_abi_version": (c_int, []),
     "simamba_strerror": (c_char_p, [c_int]),
     "simamba_scan_num_chunks": (c_int, [c_int]),
     "simamba_selective_scan_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
-                                           c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+                                           c_int, c_int, c_int, c_int, c_int, c_int,
+                                           _LL, _LL, _LL, _LL, _P]),
     "simamba_selective_scan_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                            _P, _P, _P, _P, _P, _P, _P, _P,
-                                           c_int, c_int, c_int, c_int, c_int, c_int, _P]),
-    "simamba_causal_conv1d_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+                                           c_int, c_int, c_int, c_int, c_int, c_int,
+                                           _LL, _LL, _LL, _LL, _LL, _P]),
+    "simamba_causal_conv1d_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _LL, _P]),
     "simamba_causal_conv1d_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P,
-                                          c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+                                          c_int, c_int, c_int, c_int, c_int, c_int, _LL, _LL, _P]),
     "simamba_knn_graph": (c_int, [_P, _P, _P, c_size_t, c_int, c_int, c_int, c_int, c_float, c_uint, _P]),
     "simamba_laplacian_topk": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_uint, _P]),
     "simamba_spectral_workspace_bytes": (c_size_t, [c_int, c_int]),
@@ -62,8 +66,8 @@ def load():
         fn.restype = res
         fn.argtypes = args
     got = lib.simamba_abi_version()
-    if got != 1:
-        raise RuntimeError(f"libsimamba_hip.so ABI version {got}, binding expects 1")
+    if got != ABI_VERSION:
+        raise RuntimeError(f"libsimamba_hip.so ABI version {got}, binding expects {ABI_VERSION}")
     _lib = lib
     return lib
 

@@ -22,15 +22,15 @@ class CausalConv1dFn(torch.autograd.Function):
             raise ValueError("causal_conv1d_fn: x must be (batch, dim, seqlen), weight (dim, width)")
         batch, dim, L = x.shape
         W = weight.shape[1]
-        xc = x.contiguous()
+        xc = x if (x.stride(2) == 1 and x.stride(1) == L) else x.contiguous()   # batch-strided views are fine
         wc = weight.float().contiguous()
         bc = None if bias is None else bias.float().contiguous()
-        out = torch.empty_like(xc)
+        out = torch.empty(batch, dim, L, device=x.device, dtype=x.dtype)
         silu = int(activation is not None)
         with torch.cuda.device(x.device), _lib.timed("conv1d_fwd", x.device):
             rc = lib.simamba_causal_conv1d_fwd(_lib.ptr(xc), _lib.ptr(wc), _lib.ptr(bc), _lib.ptr(out),
                                                batch, dim, L, W, silu, _lib.dtype_code(x.dtype),
-                                               _lib.stream_ptr(x.device))
+                                               xc.stride(0), _lib.stream_ptr(x.device))
         _lib.check(rc, "simamba_causal_conv1d_fwd")
         ctx.silu = silu
         ctx.w_dtype = weight.dtype
@@ -45,14 +45,14 @@ class CausalConv1dFn(torch.autograd.Function):
         batch, dim, L = xc.shape
         W = wc.shape[1]
         dout = dout.to(xc.dtype).contiguous()
-        dx = torch.empty_like(xc)
+        dx = torch.empty(batch, dim, L, device=xc.device, dtype=xc.dtype)
         dw = torch.empty_like(wc)
         db = torch.empty(dim, device=xc.device, dtype=torch.float32) if bc is not None else None
         with torch.cuda.device(xc.device), _lib.timed("conv1d_bwd", xc.device):
             rc = lib.simamba_causal_conv1d_bwd(_lib.ptr(xc), _lib.ptr(wc), _lib.ptr(bc), _lib.ptr(dout),
                                                _lib.ptr(dx), _lib.ptr(dw), _lib.ptr(db),
                                                batch, dim, L, W, ctx.silu, _lib.dtype_code(xc.dtype),
-                                               _lib.stream_ptr(xc.device))
+                                               xc.stride(0), 0, _lib.stream_ptr(xc.device))
         _lib.check(rc, "simamba_causal_conv1d_bwd")
         return dx, dw.to(ctx.w_dtype), None if db is None else db.to(ctx.b_dtype), None
 

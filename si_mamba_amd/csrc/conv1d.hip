@@ -28,6 +28,8 @@ struct ConvArgs {
   int vec;
   int ppr;         // padded packs per row (power of two, >= 16)
   int bchunk;      // batch samples per workgroup
+  long long x_bs;  // batch stride (elements) of x
+  long long o_bs;  // batch stride (elements) of out (fwd: contiguous) / dx (bwd)
 };
 
 template <typename T>
@@ -65,8 +67,8 @@ __global__ __launch_bounds__(kConvThreads) void conv1d_fwd_kernel(ConvArgs p) {
   const int b1 = min(b0 + p.bchunk, p.batch);
   const bool vec = p.vec != 0;
   for (int b = b0; b < b1; ++b) {
-    const T* row = xg + (static_cast<size_t>(b) * D + d) * L;
-    T* orow = og + (static_cast<size_t>(b) * D + d) * L;
+    const T* row = xg + static_cast<size_t>(b) * p.x_bs + static_cast<size_t>(d) * L;
+    T* orow = og + static_cast<size_t>(b) * p.o_bs + static_cast<size_t>(d) * L;
     for (int pk = (p.ppr >= kConvThreads ? threadIdx.x : threadIdx.x % p.ppr); pk * kPack < L;
          pk += (p.ppr >= kConvThreads ? kConvThreads : p.ppr)) {
       const int t0 = pk * kPack;
@@ -107,14 +109,16 @@ __global__ __launch_bounds__(kConvThreads) void conv1d_bwd_kernel(ConvArgs p) {
   const bool vec = p.vec != 0;
   float gw[4] = {0.f, 0.f, 0.f, 0.f}, gb = 0.f;
   for (int b = b0; b < b1; ++b) {
-    const size_t roff = (static_cast<size_t>(b) * D + dc) * L;
+    const size_t roff = (static_cast<size_t>(b) * D + dc) * L;                      // dout: contiguous
+    const size_t xoff = static_cast<size_t>(b) * p.x_bs + static_cast<size_t>(dc) * L;
+    const size_t doff = static_cast<size_t>(b) * p.o_bs + static_cast<size_t>(dc) * L;
     for (int pk = (p.ppr >= kConvThreads ? threadIdx.x : threadIdx.x % p.ppr); pk * kPack < L;
          pk += (p.ppr >= kConvThreads ? kConvThreads : p.ppr)) {
       const int t0 = pk * kPack;
       float xp[kPack], xc[kPack], xn[kPack], gc[kPack], gn[kPack];
-      load_pack<T>(xg + roff, t0 - kPack, L, vec, xp);
-      load_pack<T>(xg + roff, t0, L, vec, xc);
-      load_pack<T>(xg + roff, t0 + kPack, L, vec, xn);
+      load_pack<T>(xg + xoff, t0 - kPack, L, vec, xp);
+      load_pack<T>(xg + xoff, t0, L, vec, xc);
+      load_pack<T>(xg + xoff, t0 + kPack, L, vec, xn);
       load_pack<T>(gg + roff, t0, L, vec, gc);
       load_pack<T>(gg + roff, t0 + kPack, L, vec, gn);
       // x[t0-3 .. t0+6], dout[t0 .. t0+6]
@@ -144,7 +148,7 @@ __global__ __launch_bounds__(kConvThreads) void conv1d_bwd_kernel(ConvArgs p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) gw[j] = fmaf(dpre[i], xw[i + j], gw[j]);
       }
-      if (dvalid) store_items<T, kPack>(dxg + roff + t0, L - t0, vec, dx);
+      if (dvalid) store_items<T, kPack>(dxg + doff + t0, L - t0, vec, dx);
     }
   }
   // 16-lane rows never straddle channels (ppr is a multiple of 16)
@@ -204,7 +208,7 @@ static int check_conv(const void* x, const float* w, int batch, int dim, int seq
 
 extern "C" int simamba_causal_conv1d_fwd(const void* x, const float* w, const float* bias, void* out,
                                          int batch, int dim, int seqlen, int width, int silu,
-                                         int io_dtype, void* stream) {
+                                         int io_dtype, long long x_bstride, void* stream) {
   int rc = check_conv(x, w, batch, dim, seqlen, width, io_dtype);
   if (rc) return rc;
   if (!out) return SIMAMBA_E_NULLPTR;
@@ -213,7 +217,9 @@ extern "C" int simamba_causal_conv1d_fwd(const void* x, const float* w, const fl
   a.x = x; a.w = w; a.bias = bias; a.out = out;
   a.batch = batch; a.dim = dim; a.seqlen = seqlen; a.width = width; a.silu = silu;
   const int dblocks = fill_common(a, io_dtype);
-  a.vec = a.vec && al16(x) && al16(out);
+  a.x_bs = x_bstride ? x_bstride : static_cast<long long>(dim) * seqlen;
+  a.o_bs = static_cast<long long>(dim) * seqlen;
+  a.vec = a.vec && al16(x) && al16(out) && (a.x_bs * (io_dtype == SIMAMBA_F32 ? 4 : 2)) % 16 == 0;
   dim3 grid(dblocks, (batch + a.bchunk - 1) / a.bchunk);
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (io_dtype == SIMAMBA_F32)
@@ -225,7 +231,8 @@ extern "C" int simamba_causal_conv1d_fwd(const void* x, const float* w, const fl
 
 extern "C" int simamba_causal_conv1d_bwd(const void* x, const float* w, const float* bias, const void* dout,
                                          void* dx, float* dw, float* dbias, int batch, int dim, int seqlen,
-                                         int width, int silu, int io_dtype, void* stream) {
+                                         int width, int silu, int io_dtype, long long x_bstride,
+                                         long long dx_bstride, void* stream) {
   int rc = check_conv(x, w, batch, dim, seqlen, width, io_dtype);
   if (rc) return rc;
   if (!dout || !dx || !dw) return SIMAMBA_E_NULLPTR;
@@ -241,7 +248,10 @@ extern "C" int simamba_causal_conv1d_bwd(const void* x, const float* w, const fl
   a.x = x; a.w = w; a.bias = bias; a.out = dx; a.dout = dout; a.dw = dw; a.dbias = dbias;
   a.batch = batch; a.dim = dim; a.seqlen = seqlen; a.width = width; a.silu = silu;
   const int dblocks = fill_common(a, io_dtype);
-  a.vec = a.vec && al16(x) && al16(dx) && al16(dout);
+  a.x_bs = x_bstride ? x_bstride : static_cast<long long>(dim) * seqlen;
+  a.o_bs = dx_bstride ? dx_bstride : static_cast<long long>(dim) * seqlen;
+  const long long esz_ = io_dtype == SIMAMBA_F32 ? 4 : 2;
+  a.vec = a.vec && al16(x) && al16(dx) && al16(dout) && (a.x_bs * esz_) % 16 == 0 && (a.o_bs * esz_) % 16 == 0;
   dim3 grid(dblocks, (batch + a.bchunk - 1) / a.bchunk);
   if (io_dtype == SIMAMBA_F32)
     hipLaunchKernelGGL(conv1d_bwd_kernel<float>, grid, dim3(kConvThreads), 0, s, a);

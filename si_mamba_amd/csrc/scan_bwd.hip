@@ -58,7 +58,8 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_bwd_kernel(ScanArgs p) {
 
   for (int c = p.nchunks - 1; c >= 0; --c) {
     __syncthreads();
-    stage_bc<T, LC>(static_cast<const T*>(p.B), static_cast<const T*>(p.C), sB, sC, b, N, L, c);
+    stage_bc<T, LC>(static_cast<const T*>(p.B), static_cast<const T*>(p.C), sB, sC, b, N, L, c, p.bc_bs, p.bc_ns,
+                    p.bc_ts);
     __syncthreads();
     const bool last_chunk = (c == p.nchunks - 1);
 
@@ -85,7 +86,8 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_bwd_kernel(ScanArgs p) {
       load_items<T, kItems>(ug + off, nvalid, vec, u);
       load_items<T, kItems>(dg + off, nvalid, vec, dl);
       load_items<T, kItems>(gg + off, nvalid, vec, go);
-      if (zg) load_items<T, kItems>(zg + off, nvalid, vec, zz);
+      const size_t zoff = static_cast<size_t>(dc) * L + t0;
+      if (zg) load_items<T, kItems>(zg + static_cast<size_t>(b) * p.z_bs + zoff, nvalid, vec, zz);
       float A2[kMaxState];
       load_A_row(p.A + static_cast<size_t>(dc) * N, N, A2);
 
@@ -209,7 +211,7 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_bwd_kernel(ScanArgs p) {
       if (dvalid) {
         store_items<T, kItems>(dug + off, nvalid, vec, du);
         store_items<T, kItems>(ddg + off, nvalid, vec, ddl);
-        if (zg) store_items<T, kItems>(dzg + off, nvalid, vec, dzv);
+        if (zg) store_items<T, kItems>(dzg + static_cast<size_t>(b) * p.dz_bs + zoff, nvalid, vec, dzv);
       }
       sD = row_allreduce_sum(sD);
       sBias = row_allreduce_sum(sBias);
@@ -280,7 +282,9 @@ extern "C" int simamba_selective_scan_bwd(const void* u, const void* delta, cons
                                           const float* delta_bias, const void* dout, const float* x_ckpt,
                                           void* du, void* ddelta, float* dA, float* dB, float* dC, float* dD,
                                           void* dz, float* ddelta_bias, int batch, int dim, int seqlen,
-                                          int dstate, int io_dtype, int delta_softplus, void* stream) {
+                                          int dstate, int io_dtype, int delta_softplus, long long z_bstride,
+                                          long long dz_bstride, long long bc_bstride, long long bc_nstride,
+                                          long long bc_tstride, void* stream) {
   if (batch < 0 || dim <= 0 || seqlen < 0 || batch > 65535) return SIMAMBA_E_SHAPE;
   if (dstate < 1 || dstate > kMaxState) return SIMAMBA_E_DSTATE;
   if (io_dtype != SIMAMBA_F32 && io_dtype != SIMAMBA_BF16) return SIMAMBA_E_DTYPE;
@@ -312,8 +316,15 @@ extern "C" int simamba_selective_scan_bwd(const void* u, const void* delta, cons
   a.nchunks = nchunks;
   a.softplus = delta_softplus;
   const size_t esz = io_dtype == SIMAMBA_F32 ? 4 : 2;
+  a.z_bs = z_bstride ? z_bstride : static_cast<long long>(dim) * seqlen;
+  a.dz_bs = dz_bstride ? dz_bstride : static_cast<long long>(dim) * seqlen;
+  if (!bc_bstride && !bc_nstride && !bc_tstride) {
+    bc_bstride = static_cast<long long>(dstate) * seqlen; bc_nstride = seqlen; bc_tstride = 1;
+  }
+  a.bc_bs = bc_bstride; a.bc_ns = bc_nstride; a.bc_ts = bc_tstride;
   a.vec = ((seqlen * esz) % 16 == 0) && aligned16b(u) && aligned16b(delta) && aligned16b(dout) &&
-          aligned16b(du) && aligned16b(ddelta) && (!z || (aligned16b(z) && aligned16b(dz)));
+          aligned16b(du) && aligned16b(ddelta) &&
+          (!z || (aligned16b(z) && aligned16b(dz) && (a.z_bs * esz) % 16 == 0 && (a.dz_bs * esz) % 16 == 0));
   // channels per workgroup (16 * passes): the more, the fewer dB/dC atomics reach HBM; but keep >= 4
   // workgroups per CU so that the two resident per CU always have successors
   static const int kCand[] = {12, 8, 6, 4, 3, 2, 1};

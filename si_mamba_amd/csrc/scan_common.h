@@ -46,6 +46,8 @@ struct ScanArgs {
   int passes;     // R: channel passes per workgroup (tile = 16 * R channels)
   int vec;        // 16-byte vector access allowed
   int softplus;
+  long long z_bs, dz_bs;            // batch strides (elements) of z / dz
+  long long bc_bs, bc_ns, bc_ts;    // (batch, state, time) strides (elements) of B and C
 };
 
 // Inclusive scan over the 16 lanes of a row of the affine map (P,S) : h -> P*h + S, composed left to
@@ -108,20 +110,27 @@ __device__ __forceinline__ void load_A_row(const float* __restrict__ Arow, int N
   }
 }
 
-// stage the chunk's B and C tiles (dstate x LC) of one batch sample into LDS, zero padded
+// stage the chunk's B and C tiles (dstate x LC) of one batch sample into LDS, zero padded.
+// The global side is read through (state, time) strides: time-major (B,N,L) tensors are walked with
+// consecutive lanes on consecutive t, token-major ones (x_proj output, state stride 1) on consecutive n.
 template <typename T, int LC>
 __device__ __forceinline__ void stage_bc(const T* __restrict__ Bg, const T* __restrict__ Cg, float* sB,
-                                         float* sC, int b, int dstate, int L, int chunk) {
+                                         float* sC, int b, int dstate, int L, int chunk, long long bs,
+                                         long long ns, long long ts) {
   constexpr int LDP = LC + 4;
   const int total = dstate * LC;
-  const size_t base = static_cast<size_t>(b) * dstate * L;
+  const long long base = static_cast<long long>(b) * bs;
+  const bool token_major = (ns == 1);
   for (int i = threadIdx.x; i < total; i += kScanThreads) {
-    int n = i / LC, t = i - n * LC;
-    int gt = chunk * LC + t;
+    int n, t;
+    if (token_major) { t = i / dstate; n = i - t * dstate; }
+    else { n = i / LC; t = i - n * LC; }
+    const int gt = chunk * LC + t;
     float vb = 0.f, vc = 0.f;
     if (gt < L) {
-      vb = to_f32<T>(Bg[base + static_cast<size_t>(n) * L + gt]);
-      vc = to_f32<T>(Cg[base + static_cast<size_t>(n) * L + gt]);
+      const long long o = base + n * ns + gt * ts;
+      vb = to_f32<T>(Bg[o]);
+      vc = to_f32<T>(Cg[o]);
     }
     sB[n * LDP + t] = vb;
     sC[n * LDP + t] = vc;

@@ -30,7 +30,8 @@ __global__ __launch_bounds__(kScanThreads) void scan_fwd_kernel(ScanArgs p) {
 
   for (int c = 0; c < p.nchunks; ++c) {
     __syncthreads();
-    stage_bc<T, LC>(static_cast<const T*>(p.B), static_cast<const T*>(p.C), sB, sC, b, N, L, c);
+    stage_bc<T, LC>(static_cast<const T*>(p.B), static_cast<const T*>(p.C), sB, sC, b, N, L, c, p.bc_bs, p.bc_ns,
+                    p.bc_ts);
     __syncthreads();
 
     for (int r = 0; r < p.passes; ++r) {
@@ -46,7 +47,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_fwd_kernel(ScanArgs p) {
       float u[kItems], dl[kItems], zz[kItems], y[kItems], du[kItems];
       load_items<T, kItems>(ug + off, nvalid, vec, u);
       load_items<T, kItems>(dg + off, nvalid, vec, dl);
-      if (zg) load_items<T, kItems>(zg + off, nvalid, vec, zz);
+      if (zg) load_items<T, kItems>(zg + static_cast<size_t>(b) * p.z_bs + static_cast<size_t>(dc) * L + t0, nvalid, vec, zz);
 
       const float bias = p.delta_bias ? p.delta_bias[dc] : 0.f;
       const float Dd = p.D ? p.D[dc] : 0.f;
@@ -152,7 +153,9 @@ extern "C" int simamba_selective_scan_fwd(const void* u, const void* delta, cons
                                           const void* C, const float* D, const void* z,
                                           const float* delta_bias, void* out, float* x_ckpt,
                                           float* last_state, int batch, int dim, int seqlen, int dstate,
-                                          int io_dtype, int delta_softplus, void* stream) {
+                                          int io_dtype, int delta_softplus, long long z_bstride,
+                                          long long bc_bstride, long long bc_nstride, long long bc_tstride,
+                                          void* stream) {
   if (batch < 0 || dim <= 0 || seqlen < 0 || batch > 65535) return SIMAMBA_E_SHAPE;
   if (dstate < 1 || dstate > kMaxState) return SIMAMBA_E_DSTATE;
   if (io_dtype != SIMAMBA_F32 && io_dtype != SIMAMBA_BF16) return SIMAMBA_E_DTYPE;
@@ -165,8 +168,13 @@ extern "C" int simamba_selective_scan_fwd(const void* u, const void* delta, cons
   a.nchunks = simamba_scan_num_chunks(seqlen);
   a.softplus = delta_softplus;
   const size_t esz = io_dtype == SIMAMBA_F32 ? 4 : 2;
+  a.z_bs = z_bstride ? z_bstride : static_cast<long long>(dim) * seqlen;
+  if (!bc_bstride && !bc_nstride && !bc_tstride) {
+    bc_bstride = static_cast<long long>(dstate) * seqlen; bc_nstride = seqlen; bc_tstride = 1;
+  }
+  a.bc_bs = bc_bstride; a.bc_ns = bc_nstride; a.bc_ts = bc_tstride;
   a.vec = ((seqlen * esz) % 16 == 0) && aligned16(u) && aligned16(delta) && aligned16(out) &&
-          (!z || aligned16(z));
+          (!z || (aligned16(z) && (a.z_bs * esz) % 16 == 0));
   // channels per workgroup: amortise the (B_t,C_t) staging, but keep >= ~3 workgroups per CU
   int passes = 4;
   while (passes > 1 && static_cast<long long>(batch) * ((dim + 16 * passes - 1) / (16 * passes)) < 768) passes >>= 1;

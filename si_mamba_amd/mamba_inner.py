@@ -1,0 +1,168 @@
+"""Fused mixer body: conv1d -> x_proj -> dt_proj -> selective scan -> out_proj, one autograd node.
+
+Counterpart of ``mamba_ssm.ops.selective_scan_interface.mamba_inner_fn`` (the fast path the
+reference's mixer takes when called from models/block.py:72).  Compared with chaining the separate
+ops it never copies an activation-sized tensor:
+
+  * ``x`` and ``z`` are the two halves of the in_proj output ``xz (B, 2D, L)``; the HIP kernels read
+    them in place through a batch stride, and the backward writes ``dx`` / ``dz`` straight into the
+    halves of ONE ``dxz`` buffer (no ``chunk`` / ``cat`` / ``contiguous``);
+  * ``B_t`` / ``C_t`` are read out of the x_proj output ``(B, L, R+2N)`` through strides;
+  * every GEMM is issued in the orientation that yields an L-contiguous ``(B, *, L)`` result, so no
+    transposition kernel runs.
+
+The four projections stay library GEMMs (hipBLASLt through torch.matmul / baddbmm).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+
+
+def _w(t, dtype):
+    return t if t.dtype == dtype else t.to(dtype)
+
+
+class MambaInnerFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xz, conv_w, conv_b, x_proj_w, dt_proj_w, out_proj_w, out_proj_b, A, D, delta_bias,
+                dt_rank, d_state):
+        _lib.require_gpu(xz, "mamba_inner_fn")
+        lib = _lib.load()
+        if xz.stride(2) != 1 or xz.stride(1) != xz.shape[2]:
+            xz = xz.contiguous()
+        io = xz.dtype
+        code = _lib.dtype_code(io)
+        Bsz, twoD, L = xz.shape
+        Dm = twoD // 2
+        R, N = dt_rank, d_state
+        S = R + 2 * N
+        dev = xz.device
+        stream = _lib.stream_ptr(dev)
+        xbs = xz.stride(0)
+        x_in, z = xz[:, :Dm], xz[:, Dm:]
+
+        cw = conv_w.float().contiguous()
+        cb = None if conv_b is None else conv_b.float().contiguous()
+        Af = A.float().contiguous()
+        Df = None if D is None else D.float().contiguous()
+        bf = None if delta_bias is None else delta_bias.float().contiguous()
+        W = cw.shape[1]
+
+        x_conv = torch.empty(Bsz, Dm, L, device=dev, dtype=io)
+        with torch.cuda.device(dev), _lib.timed("conv1d_fwd", dev):
+            rc = lib.simamba_causal_conv1d_fwd(x_in.data_ptr(), cw.data_ptr(), _lib.ptr(cb), x_conv.data_ptr(),
+                                               Bsz, Dm, L, W, 1, code, xbs, stream)
+        _lib.check(rc, "simamba_causal_conv1d_fwd")
+
+        x_dbl = torch.matmul(x_conv.transpose(1, 2), _w(x_proj_w, io).t())            # (B, L, S)
+        delta = torch.matmul(_w(dt_proj_w, io), x_dbl[:, :, :R].transpose(1, 2))      # (B, D, L)
+        Bv, Cv = x_dbl[:, :, R:R + N], x_dbl[:, :, R + N:]                            # (B, L, N) views
+
+        nchunks = lib.simamba_scan_num_chunks(L)
+        need_grad = any(ctx.needs_input_grad)
+        x_ckpt = (torch.empty(Bsz, Dm, nchunks, N, device=dev, dtype=torch.float32)
+                  if (need_grad and nchunks > 1) else None)
+        y = torch.empty(Bsz, Dm, L, device=dev, dtype=io)
+        with torch.cuda.device(dev), _lib.timed("scan_fwd", dev):
+            rc = lib.simamba_selective_scan_fwd(
+                x_conv.data_ptr(), delta.data_ptr(), Af.data_ptr(), Bv.data_ptr(), Cv.data_ptr(), _lib.ptr(Df),
+                z.data_ptr(), _lib.ptr(bf), y.data_ptr(), _lib.ptr(x_ckpt), None,
+                Bsz, Dm, L, N, code, 1, xbs, x_dbl.stride(0), 1, x_dbl.stride(1), stream)
+        _lib.check(rc, "simamba_selective_scan_fwd")
+
+        out = torch.matmul(y.transpose(1, 2), _w(out_proj_w, io).t())                  # (B, L, d)
+        if out_proj_b is not None:
+            out = out + _w(out_proj_b, io)
+        ctx.dims = (R, N, W)
+        ctx.has_out_bias = out_proj_b is not None
+        ctx.param_dtypes = (conv_w.dtype, None if conv_b is None else conv_b.dtype, x_proj_w.dtype,
+                            dt_proj_w.dtype, out_proj_w.dtype, A.dtype,
+                            None if D is None else D.dtype, None if delta_bias is None else delta_bias.dtype)
+        ctx.save_for_backward(xz, x_conv, x_dbl, delta, y, cw, cb, x_proj_w, dt_proj_w, out_proj_w, Af, Df, bf,
+                              x_ckpt)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (xz, x_conv, x_dbl, delta, y, cw, cb, x_proj_w, dt_proj_w, out_proj_w, Af, Df, bf, x_ckpt) = ctx.saved_tensors
+        lib = _lib.load()
+        R, N, W = ctx.dims
+        io = xz.dtype
+        code = _lib.dtype_code(io)
+        Bsz, twoD, L = xz.shape
+        Dm = twoD // 2
+        S = R + 2 * N
+        dev = xz.device
+        stream = _lib.stream_ptr(dev)
+        xbs = xz.stride(0)
+        dout = dout.to(io)
+        f32 = dict(device=dev, dtype=torch.float32)
+
+        # out_proj
+        d_out_w = torch.bmm(dout.transpose(1, 2), y.transpose(1, 2)).sum(0)           # (d, D)
+        d_out_b = dout.sum((0, 1)) if ctx.has_out_bias else None
+        dy = torch.matmul(_w(out_proj_w, io).t(), dout.transpose(1, 2))               # (B, D, L)
+
+        # selective scan
+        dxz = torch.empty_like(xz)
+        du = torch.empty(Bsz, Dm, L, device=dev, dtype=io)
+        ddelta = torch.empty(Bsz, Dm, L, device=dev, dtype=io)
+        dA = torch.empty(Dm, N, **f32)
+        dB = torch.empty(Bsz, N, L, **f32)
+        dC = torch.empty(Bsz, N, L, **f32)
+        dD = torch.empty(Dm, **f32) if Df is not None else None
+        dbias = torch.empty(Dm, **f32) if bf is not None else None
+        Bv, Cv = x_dbl[:, :, R:R + N], x_dbl[:, :, R + N:]
+        z, dz = xz[:, Dm:], dxz[:, Dm:]
+        with torch.cuda.device(dev), _lib.timed("scan_bwd", dev):
+            rc = lib.simamba_selective_scan_bwd(
+                x_conv.data_ptr(), delta.data_ptr(), Af.data_ptr(), Bv.data_ptr(), Cv.data_ptr(), _lib.ptr(Df),
+                z.data_ptr(), _lib.ptr(bf), dy.data_ptr(), _lib.ptr(x_ckpt),
+                du.data_ptr(), ddelta.data_ptr(), dA.data_ptr(), dB.data_ptr(), dC.data_ptr(), _lib.ptr(dD),
+                dz.data_ptr(), _lib.ptr(dbias), Bsz, Dm, L, N, code, 1,
+                xbs, dxz.stride(0), x_dbl.stride(0), 1, x_dbl.stride(1), stream)
+        _lib.check(rc, "simamba_selective_scan_bwd")
+
+        # dt_proj / x_proj
+        dx_dbl = torch.empty(Bsz, L, S, device=dev, dtype=io)
+        dx_dbl[:, :, :R].copy_(torch.matmul(ddelta.transpose(1, 2), _w(dt_proj_w, io)))
+        dx_dbl[:, :, R:R + N].copy_(dB.transpose(1, 2))
+        dx_dbl[:, :, R + N:].copy_(dC.transpose(1, 2))
+        d_dt_w = torch.bmm(ddelta, x_dbl[:, :, :R]).sum(0)                             # (D, R)
+        d_x_w = torch.bmm(dx_dbl.transpose(1, 2), x_conv.transpose(1, 2)).sum(0)       # (S, D)
+        # dx_conv = du + x_proj_w^T @ dx_dbl^T, accumulated in place by the GEMM (beta = 1)
+        wxT = _w(x_proj_w, io).t().unsqueeze(0).expand(Bsz, -1, -1)
+        torch.baddbmm(du, wxT, dx_dbl.transpose(1, 2), out=du)
+
+        # conv1d: dx goes straight into the first half of dxz
+        dcw = torch.empty_like(cw)
+        dcb = torch.empty(Dm, **f32) if cb is not None else None
+        with torch.cuda.device(dev), _lib.timed("conv1d_bwd", dev):
+            rc = lib.simamba_causal_conv1d_bwd(xz.data_ptr(), cw.data_ptr(), _lib.ptr(cb), du.data_ptr(),
+                                               dxz.data_ptr(), dcw.data_ptr(), _lib.ptr(dcb),
+                                               Bsz, Dm, L, W, 1, code, xbs, dxz.stride(0), stream)
+        _lib.check(rc, "simamba_causal_conv1d_bwd")
+
+        t_cw, t_cb, t_xw, t_dtw, t_ow, t_A, t_D, t_b = ctx.param_dtypes
+        return (dxz, dcw.to(t_cw), None if dcb is None else dcb.to(t_cb), d_x_w.to(t_xw), d_dt_w.to(t_dtw),
+                d_out_w.to(t_ow), None if d_out_b is None else d_out_b.to(out_proj_w.dtype), dA.to(t_A),
+                None if dD is None else dD.to(t_D), None if dbias is None else dbias.to(t_b), None, None)
+
+
+def mamba_inner_fn(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight,
+                   out_proj_bias, A, D=None, delta_bias=None, dt_rank=None, d_state=None):
+    """xz: (B, 2D, L); conv1d_weight: (D, W) or (D, 1, W); returns (B, L, d_model).
+
+    ``B``/``C`` are always input-dependent (taken from x_proj), delta_softplus is always on: the only
+    configuration the reference's mixer uses.
+    """
+    if conv1d_weight.dim() == 3:
+        conv1d_weight = conv1d_weight.squeeze(1)
+    if dt_rank is None:
+        dt_rank = delta_proj_weight.shape[1]
+    if d_state is None:
+        d_state = (x_proj_weight.shape[0] - dt_rank) // 2
+    return MambaInnerFn.apply(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight,
+                              out_proj_bias, A, D, delta_bias, dt_rank, d_state)

@@ -22,6 +22,7 @@ import torch
 import torch.nn as nn
 
 from .causal_conv1d import causal_conv1d_fn
+from .mamba_inner import mamba_inner_fn
 from .selective_scan import selective_scan_fn
 
 
@@ -87,12 +88,19 @@ class Mamba(nn.Module):
         xz = torch.matmul(self.in_proj.weight, hidden_states.transpose(1, 2))
         if self.in_proj.bias is not None:
             xz = xz + self.in_proj.bias.to(xz.dtype)[None, :, None]
+        A = -torch.exp(self.A_log.float())
+        if self.use_fast_path:
+            # one autograd node, no activation-sized copies (mamba_inner.py)
+            return mamba_inner_fn(xz, self.conv1d.weight, self.conv1d.bias, self.x_proj.weight,
+                                  self.dt_proj.weight, self.out_proj.weight, self.out_proj.bias, A,
+                                  self.D.float(), delta_bias=self.dt_proj.bias.float(),
+                                  dt_rank=self.dt_rank, d_state=self.d_state)
+        # reference composition of the separate ops (same kernels; copies the strided views)
         x, z = xz.chunk(2, dim=1)
         x = causal_conv1d_fn(x, self.conv1d.weight.squeeze(1), self.conv1d.bias, self.activation)
         x_dbl = torch.matmul(x.transpose(1, 2), self.x_proj.weight.t())            # (B, L, R+2N)
         dt, Bm, Cm = torch.split(x_dbl, [self.dt_rank, self.d_state, self.d_state], dim=-1)
         delta = torch.matmul(self.dt_proj.weight, dt.transpose(1, 2))              # (B, D, L), bias in scan
-        A = -torch.exp(self.A_log.float())
         y = selective_scan_fn(x, delta, A, Bm.transpose(1, 2), Cm.transpose(1, 2), self.D.float(), z=z,
                               delta_bias=self.dt_proj.bias.float(), delta_softplus=True)
         out = torch.matmul(y.transpose(1, 2), self.out_proj.weight.t())

@@ -12,6 +12,11 @@ import torch
 from . import _lib
 
 
+def _rows_contiguous(t):
+    """(B, D, L) view whose (D, L) planes are dense: only the batch stride may differ."""
+    return t.dim() == 3 and t.stride(2) == 1 and t.stride(1) == t.shape[2]
+
+
 def _bc_bnl(M, name):
     if M.dim() == 4:
         if M.shape[1] != 1:
@@ -41,10 +46,14 @@ class SelectiveScanFn(torch.autograd.Function):
         uc = u.contiguous()
         dc = delta.to(io).contiguous()
         Ac = A.float().contiguous()
-        Bc = B3.to(io).contiguous()
-        Cc = C3.to(io).contiguous()
+        # B, C are read through their strides (no transposition copy) when both share them
+        Bc, Cc = B3.to(io), C3.to(io)
+        if Bc.stride() != Cc.stride() or min(Bc.stride()) < 0:
+            Bc, Cc = Bc.contiguous(), Cc.contiguous()
         Dc = None if D is None else D.float().contiguous()
-        zc = None if z is None else z.to(io).contiguous()
+        zc = None if z is None else z.to(io)
+        if zc is not None and not _rows_contiguous(zc):
+            zc = zc.contiguous()
         bc = None if delta_bias is None else delta_bias.float().contiguous()
         out = torch.empty_like(uc)
         nchunks = lib.simamba_scan_num_chunks(L)
@@ -57,7 +66,9 @@ class SelectiveScanFn(torch.autograd.Function):
             rc = lib.simamba_selective_scan_fwd(
                 _lib.ptr(uc), _lib.ptr(dc), _lib.ptr(Ac), _lib.ptr(Bc), _lib.ptr(Cc), _lib.ptr(Dc),
                 _lib.ptr(zc), _lib.ptr(bc), _lib.ptr(out), _lib.ptr(x_ckpt), _lib.ptr(last),
-                batch, dim, L, N, code, int(bool(delta_softplus)), _lib.stream_ptr(u.device))
+                batch, dim, L, N, code, int(bool(delta_softplus)),
+                0 if zc is None else zc.stride(0), Bc.stride(0), Bc.stride(1), Bc.stride(2),
+                _lib.stream_ptr(u.device))
         _lib.check(rc, "simamba_selective_scan_fwd")
         ctx.delta_softplus = bool(delta_softplus)
         ctx.has = (D is not None, z is not None, delta_bias is not None)
@@ -94,7 +105,8 @@ class SelectiveScanFn(torch.autograd.Function):
                 _lib.ptr(zc), _lib.ptr(bc), _lib.ptr(dout), _lib.ptr(x_ckpt),
                 _lib.ptr(du), _lib.ptr(ddelta), _lib.ptr(dA), _lib.ptr(dB), _lib.ptr(dC), _lib.ptr(dD),
                 _lib.ptr(dz), _lib.ptr(dbias), batch, dim, L, N, _lib.dtype_code(io),
-                int(ctx.delta_softplus), _lib.stream_ptr(uc.device))
+                int(ctx.delta_softplus), 0 if zc is None else zc.stride(0), 0,
+                Bc.stride(0), Bc.stride(1), Bc.stride(2), _lib.stream_ptr(uc.device))
         _lib.check(rc, "simamba_selective_scan_bwd")
         dt_delta, dt_B, dt_C, dt_D, dt_z, dt_bias, dt_A = ctx.in_dtypes
         dB = dB.to(dt_B)
