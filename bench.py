@@ -61,6 +61,8 @@ def cpu_baseline(npts, groups, seed=0):
     """Oracle port of the same training step (same architecture, fp32) on a bounded 2-cloud sample."""
     from oracle import scan_ref, spectral_ref
     from si_mamba_amd.point_mamba import PointMamba, default_config
+    # the oracle's per-timestep torch ops are tiny: more threads only add fork/join latency
+    torch.set_num_threads(min(16, torch.get_num_threads()))
     torch.manual_seed(0)
     cfg = default_config(num_group=groups, drop_path=0.)
     m = PointMamba(cfg)

@@ -22,7 +22,7 @@ import torch
 import torch.nn as nn
 
 from .causal_conv1d import causal_conv1d_fn
-from .mamba_inner import mamba_inner_fn
+from .mamba_inner import in_proj_fn, mamba_inner_fn
 from .selective_scan import selective_scan_fn
 
 
@@ -84,18 +84,19 @@ class Mamba(nn.Module):
                 "step-wise decoding caches are not on the SI-Mamba path (no reference runner passes "
                 "inference_params; models/block.py:75-76 is never reached)")
         batch, seqlen, _ = hidden_states.shape
-        # (2D, d) @ (B, d, L) -> (B, 2D, L): L is the contiguous axis the HIP kernels stream along
-        xz = torch.matmul(self.in_proj.weight, hidden_states.transpose(1, 2))
-        if self.in_proj.bias is not None:
-            xz = xz + self.in_proj.bias.to(xz.dtype)[None, :, None]
         A = -torch.exp(self.A_log.float())
+        # (2D, d) @ (B, d, L) -> (B, 2D, L): L is the contiguous axis the HIP kernels stream along
         if self.use_fast_path:
+            xz = in_proj_fn(hidden_states, self.in_proj.weight, self.in_proj.bias)
             # one autograd node, no activation-sized copies (mamba_inner.py)
             return mamba_inner_fn(xz, self.conv1d.weight, self.conv1d.bias, self.x_proj.weight,
                                   self.dt_proj.weight, self.out_proj.weight, self.out_proj.bias, A,
                                   self.D.float(), delta_bias=self.dt_proj.bias.float(),
                                   dt_rank=self.dt_rank, d_state=self.d_state)
-        # reference composition of the separate ops (same kernels; copies the strided views)
+        # reference composition of the separate ops (same kernels; torch.matmul / chunk copy the views)
+        xz = torch.matmul(self.in_proj.weight, hidden_states.transpose(1, 2))
+        if self.in_proj.bias is not None:
+            xz = xz + self.in_proj.bias.to(xz.dtype)[None, :, None]
         x, z = xz.chunk(2, dim=1)
         x = causal_conv1d_fn(x, self.conv1d.weight.squeeze(1), self.conv1d.bias, self.activation)
         x_dbl = torch.matmul(x.transpose(1, 2), self.x_proj.weight.t())            # (B, L, R+2N)
