@@ -4,9 +4,9 @@
 //   models/point_mamba.py:620-661 / :664-715   (pairwise distances, topk, index_put adjacency)
 //   models/point_mamba.py:717-761 / :764-814   (Python loop of torch.linalg.eigh -> cuSOLVER)
 //   models/point_mamba.py:820                  (torch.sort of each selected eigenvector)
-// The G x G problem (G <= 128) lives entirely in LDS (matrix + eigenvector basis = 2*G*(G+1)*4
-// <= 129 KiB of the CU's 160 KiB); the eigensolver is a cyclic two-sided Jacobi with the
-// round-robin (tournament) ordering, G/2 disjoint rotations per step applied by all 1024 lanes.
+// The G x G problem (G <= 128) lives entirely in LDS (matrix + eigenvector basis = 2*128*132*4
+// = 132 KiB of the CU's 160 KiB); the eigensolver is a cyclic one-sided (Hestenes) Jacobi with the
+// round-robin (tournament) ordering: G/2 disjoint column pairs per step, one 16-lane DPP row per pair.
 // This file is compiled WITHOUT fast-math and with -ffp-contract=off so that distances and the
 // Laplacian entries round exactly like the reference's unfused torch ops.
 #include "common.h"
@@ -107,7 +107,18 @@ __global__ __launch_bounds__(kGraphThreads) void knn_graph_kernel(const float* _
 }
 
 // ---------------------------------------------------------------------------------------------
-// Laplacian + Jacobi eigensolver + selection + argsort, one sample per workgroup
+// Laplacian + Jacobi eigensolver + selection + argsort, one sample per workgroup.
+//
+// One-sided (Hestenes) Jacobi on W = S + 2I (S = the mirrored lower triangle of the Laplacian; its
+// spectrum lies in [-1, 3] by Gershgorin, so the shifted matrix is positive definite): column pairs (p,q)
+// of W are rotated until all columns are mutually orthogonal.  Then W = (S + 2I) V with V orthogonal and
+// W^T W diagonal, i.e. w_j = lambda'_j v_j: the eigenvector is the normalised column, the eigenvalue its
+// norm minus the shift -- no eigenvector matrix is accumulated, the whole state is ONE G x G LDS image.
+// Why one-sided: a 16-lane DPP row owns one pair -- it forms the three inner products (alpha, beta, gamma)
+// with a DPP all-reduce, derives the rotation redundantly in every lane and applies it to its slice of the
+// two columns (16-byte LDS accesses), so a step of G/2 disjoint pairs needs ONE workgroup barrier (the
+// two-sided form needs three plus a serial parameter phase and measured 6.2 ms per batch of 64).
+// Columns are stored as contiguous rows Wt[p][:].
 struct EigArgs {
   const float* adj;
   float* evals;
@@ -119,142 +130,149 @@ struct EigArgs {
   unsigned flags;
 };
 
+constexpr int kEigLD = kSpecMaxG + 4;     // row stride of the LDS image (floats), keeps rows 16-B aligned
+constexpr int kEigVec = kSpecMaxG / 64;   // 16-byte chunks of a column per lane (lane l: floats 4l.., 64+4l..)
+constexpr float kEigShift = 2.0f;
+
 __global__ __launch_bounds__(kEigThreads) void laplacian_eig_kernel(EigArgs p) {
-  extern __shared__ float sm[];
-  const int G = p.G, LD = G + 1;
-  float* S = sm;                  // [G][LD]  matrix being diagonalised
-  float* V = S + G * LD;          // [G][LD]  accumulated rotations (columns = eigenvectors)
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int G = p.G;
+  constexpr int LD = kEigLD;
+  float* Wt = sm;                 // [kSpecMaxG][LD]  column p of W at Wt[p*LD + i]; rows >= G unused
+  float* Vt = Wt;                 // after convergence the columns are normalised in place: V
   __shared__ float sDeg[kSpecMaxG];
-  __shared__ float sCs[kSpecMaxG];        // (s, tau = s / (1 + c)) per pair
-  __shared__ float sPiv[2 * kSpecMaxG];   // rotated pivot diagonal (a_pp', a_qq') per pair
-  __shared__ int sPq[kSpecMaxG];          // (p, q) per pair
+  __shared__ float sEval[kSpecMaxG];
   __shared__ int sRank[kSpecMaxG];        // eigenvalue index by ascending rank
   __shared__ int sSel[kSpecMaxG];
   __shared__ float sSign[kSpecMaxG];
   __shared__ int sFlag;
   const int tid = threadIdx.x;
+  const int lane16 = tid & 15;
+  const int grp = tid >> 4;               // 64 groups of 16 lanes: one column pair each
   const float* A = p.adj + static_cast<size_t>(blockIdx.x) * G * G;
 
-  // A <- (A + A^T) / 2 into V (scratch), degrees, Laplacian lower triangle mirrored into S
-  for (int e = tid; e < G * G; e += kEigThreads) {
-    const int i = e / G, j = e - i * G;
-    V[i * LD + j] = (A[i * G + j] + A[j * G + i]) / 2.f;
-  }
-  __syncthreads();
+  // degrees of (A + A^T)/2, then the Laplacian's lower triangle mirrored (+ shift) into Wt
   if (tid < G) {
     float s = 0.f;
-    for (int j = 0; j < G; ++j) s = s + V[tid * LD + j];
+    for (int j = 0; j < G; ++j) s = s + (A[tid * G + j] + A[j * G + tid]) / 2.f;
     sDeg[tid] = s;
   }
+  for (int e = tid; e < kSpecMaxG * LD; e += kEigThreads) Wt[e] = 0.f;
   __syncthreads();
   const bool msym = p.flags & SIMAMBA_SPEC_MATRIX_SYM;
   for (int e = tid; e < G * G; e += kEigThreads) {
     const int i = e / G, j = e - i * G;
     if (i >= j) {   // eigh(UPLO='L'): only the lower triangle of the (unsymmetric) L is read
+      const float aij = (A[i * G + j] + A[j * G + i]) / 2.f;
       float l;
       if (msym) {
         const float di = powf(sDeg[i], -0.5f), dj = powf(sDeg[j], -0.5f);
-        l = (i == j ? 1.f : 0.f) - (di * V[i * LD + j]) * dj;
+        l = (i == j ? 1.f : 0.f) - (di * aij) * dj;
       } else {
         const float dinv = 1.0f / (sDeg[i] + 1e-6f);
-        l = (i == j ? 1.f : 0.f) - dinv * V[i * LD + j];
+        l = (i == j ? 1.f : 0.f) - dinv * aij;
       }
-      S[i * LD + j] = l;
-      S[j * LD + i] = l;
+      const float w = l + (i == j ? kEigShift : 0.f);
+      Wt[i * LD + j] = w;
+      Wt[j * LD + i] = w;
     }
   }
   __syncthreads();
-  for (int e = tid; e < G * G; e += kEigThreads) {
-    const int i = e / G, j = e - i * G;
-    V[i * LD + j] = (i == j) ? 1.f : 0.f;
-  }
-  __syncthreads();
 
-  // ---- cyclic Jacobi, tournament ordering ------------------------------------------------
+  // ---- cyclic one-sided Jacobi, tournament ordering: group `grp` owns pair `grp` of each step ---------
   const int M = G + (G & 1);      // players (one dummy when G is odd)
-  const int half = M / 2;
-  for (int sweep = 0; sweep < 30; ++sweep) {
+  const int half = M / 2;         // <= 64 pairs per step
+  // |cos(w_p, w_q)| below which a pair counts as orthogonal.  The fp32 inner product of two 128-vectors
+  // carries ~sqrt(G) * 2^-24 ~ 7e-7 of relative noise, so a tighter bound never terminates (measured: all
+  // 24 sweeps); rotations are still applied down to kApply so a sweep only refines.
+  const float kDone = 1.5e-6f, kApply = 2.0e-7f;
+  for (int sweep = 0; sweep < 24; ++sweep) {
     if (tid == 0) sFlag = 0;
     __syncthreads();
     for (int step = 0; step < M - 1; ++step) {
-      if (tid < half) {
-        int a, b;
-        if (tid == 0) { a = M - 1; b = step % (M - 1); }
-        else { a = (step + tid) % (M - 1); b = (step + M - 1 - tid) % (M - 1); }
-        int pp = a < b ? a : b, qq = a < b ? b : a;
-        // Rutishauser's form: x' = x - s (y + tau x), y' = y + s (x - tau y), tau = s / (1 + c).
-        // (c x - s y with c rounded to 1 for small angles grows every norm by t^2/2 per rotation.)
-        float s = 0.f, tq = 0.f, dpp_ = 0.f, dqq_ = 0.f;
+      if (grp < half) {
+        // step < M-1 and grp < M/2, so one conditional subtraction replaces each modulo
+        int a = step + grp, b = step + (M - 1) - grp;
+        a = a >= M - 1 ? a - (M - 1) : a;
+        b = b >= M - 1 ? b - (M - 1) : b;
+        if (grp == 0) { a = M - 1; b = step; }
+        const int pp = a < b ? a : b, qq = a < b ? b : a;
         if (qq < G) {
-          const float apq = S[pp * LD + qq];
-          const float app = S[pp * LD + pp], aqq = S[qq * LD + qq];
-          dpp_ = app; dqq_ = aqq;
-          if (fabsf(apq) > 1e-12f * (fabsf(app) + fabsf(aqq)) + 1e-37f) {
-            const float theta = (aqq - app) / (2.f * apq);
-            const float t = (theta >= 0.f ? 1.f : -1.f) / (fabsf(theta) + sqrtf(1.f + theta * theta));
-            const float c = 1.f / sqrtf(1.f + t * t);
-            s = t * c;
-            tq = s / (1.f + c);
-            dpp_ = app - t * apq;
-            dqq_ = aqq + t * apq;
-            if (fabsf(apq) > 5e-8f * (fabsf(app) + fabsf(aqq)) + 1e-10f) sFlag = 1;
+          float4 wp[kEigVec], wq[kEigVec];
+          float al = 0.f, be = 0.f, ga = 0.f;
+#pragma unroll
+          for (int k = 0; k < kEigVec; ++k) {    // entries >= G of a row are zero and stay zero
+            wp[k] = *reinterpret_cast<const float4*>(Wt + pp * LD + 64 * k + 4 * lane16);
+            wq[k] = *reinterpret_cast<const float4*>(Wt + qq * LD + 64 * k + 4 * lane16);
+            al += wp[k].x * wp[k].x + wp[k].y * wp[k].y + wp[k].z * wp[k].z + wp[k].w * wp[k].w;
+            be += wq[k].x * wq[k].x + wq[k].y * wq[k].y + wq[k].z * wq[k].z + wq[k].w * wq[k].w;
+            ga += wp[k].x * wq[k].x + wp[k].y * wq[k].y + wp[k].z * wq[k].z + wp[k].w * wq[k].w;
           }
-        } else {
-          qq = -1;
-        }
-        sPq[2 * tid] = pp; sPq[2 * tid + 1] = qq;
-        sCs[2 * tid] = s; sCs[2 * tid + 1] = tq;
-        sPiv[2 * tid] = dpp_; sPiv[2 * tid + 1] = dqq_;
-      }
-      __syncthreads();
-      // rows: S <- J^T S
-      for (int e = tid; e < half * G; e += kEigThreads) {
-        const int pr = e / G, j = e - pr * G;
-        const int pp = sPq[2 * pr], qq = sPq[2 * pr + 1];
-        const float s = sCs[2 * pr], tq = sCs[2 * pr + 1];
-        if (qq >= 0 && s != 0.f) {
-          const float x = S[pp * LD + j], y = S[qq * LD + j];
-          S[pp * LD + j] = x - s * (y + tq * x);
-          S[qq * LD + j] = y + s * (x - tq * y);
-        }
-      }
-      __syncthreads();
-      // columns: S <- S J, V <- V J
-      for (int e = tid; e < half * G; e += kEigThreads) {
-        const int pr = e / G, i = e - pr * G;
-        const int pp = sPq[2 * pr], qq = sPq[2 * pr + 1];
-        const float s = sCs[2 * pr], tq = sCs[2 * pr + 1];
-        if (qq >= 0 && s != 0.f) {
-          const float x = S[i * LD + pp], y = S[i * LD + qq];
-          float xn = x - s * (y + tq * x), yn = y + s * (x - tq * y);
-          // the 2x2 pivot block is known in closed form: exact zero off-diagonal, a_pp - t a_pq, a_qq + t a_pq
-          if (i == pp) { xn = sPiv[2 * pr]; yn = 0.f; }
-          if (i == qq) { xn = 0.f; yn = sPiv[2 * pr + 1]; }
-          S[i * LD + pp] = xn;
-          S[i * LD + qq] = yn;
-          const float vx = V[i * LD + pp], vy = V[i * LD + qq];
-          V[i * LD + pp] = vx - s * (vy + tq * vx);
-          V[i * LD + qq] = vy + s * (vx - tq * vy);
+          al = row_allreduce_sum(al);
+          be = row_allreduce_sum(be);
+          ga = row_allreduce_sum(ga);
+          const float g2 = ga * ga, ab = al * be;
+          if (g2 > (kApply * kApply) * ab && fabsf(ga) > 1e-30f) {   // uniform over the 16 lanes
+            // Any (s, tq) with tq = s / (1 + sqrt(1 - s^2)) is an exactly orthogonal rotation in the
+            // Rutishauser form below, so the hardware rcp / rsq approximations only perturb the ANGLE.
+            const float zeta = (be - al) * __builtin_amdgcn_rcpf(2.f * ga);
+            const float t = (zeta >= 0.f ? 1.f : -1.f) *
+                            __builtin_amdgcn_rcpf(fabsf(zeta) + __builtin_amdgcn_sqrtf(1.f + zeta * zeta));
+            const float s = t * __builtin_amdgcn_rsqf(1.f + t * t);
+            const float c = __builtin_amdgcn_sqrtf(fmaxf(1.f - s * s, 0.f));
+            const float tq = s * __builtin_amdgcn_rcpf(1.f + c);
+#pragma unroll
+            for (int k = 0; k < kEigVec; ++k) {
+              float4 x = wp[k], y = wq[k], xn, yn;
+              xn.x = x.x - s * (y.x + tq * x.x); yn.x = y.x + s * (x.x - tq * y.x);
+              xn.y = x.y - s * (y.y + tq * x.y); yn.y = y.y + s * (x.y - tq * y.y);
+              xn.z = x.z - s * (y.z + tq * x.z); yn.z = y.z + s * (x.z - tq * y.z);
+              xn.w = x.w - s * (y.w + tq * x.w); yn.w = y.w + s * (x.w - tq * y.w);
+              *reinterpret_cast<float4*>(Wt + pp * LD + 64 * k + 4 * lane16) = xn;
+              *reinterpret_cast<float4*>(Wt + qq * LD + 64 * k + 4 * lane16) = yn;
+            }
+            if (lane16 == 0 && g2 > (kDone * kDone) * ab) sFlag = 1;
+          }
         }
       }
       __syncthreads();
     }
-    if (sFlag == 0) break;
+    if (sFlag == 0) break;      // measured: 7-9 sweeps at G = 64 / 128
     __syncthreads();
   }
 
+  // ---- eigenvalue = column norm - shift; eigenvector = normalised column (in place) -------------------
+  for (int col = grp; col < G; col += kEigThreads / 16) {
+    float4 w[kEigVec];
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < kEigVec; ++k) {
+      w[k] = *reinterpret_cast<const float4*>(Wt + col * LD + 64 * k + 4 * lane16);
+      acc += w[k].x * w[k].x + w[k].y * w[k].y + w[k].z * w[k].z + w[k].w * w[k].w;
+    }
+    acc = row_allreduce_sum(acc);
+    const float nrm = sqrtf(acc);
+    const float inv = 1.0f / nrm;
+#pragma unroll
+    for (int k = 0; k < kEigVec; ++k) {
+      w[k].x *= inv; w[k].y *= inv; w[k].z *= inv; w[k].w *= inv;
+      *reinterpret_cast<float4*>(Wt + col * LD + 64 * k + 4 * lane16) = w[k];
+    }
+    if (lane16 == 0) sEval[col] = nrm - kEigShift;
+  }
+  __syncthreads();
   // ---- sort eigenvalues ascending (rank sort, ties by index) ------------------------------
   if (tid < G) {
-    const float li = S[tid * LD + tid];
+    const float li = sEval[tid];
     int rk = 0;
     for (int j = 0; j < G; ++j) {
-      const float lj = S[j * LD + j];
+      const float lj = sEval[j];
       rk += (lj < li) || (lj == li && j < tid);
     }
     sRank[rk] = tid;
   }
   __syncthreads();
-  if (p.all_evals && tid < G) p.all_evals[static_cast<size_t>(blockIdx.x) * G + tid] = S[sRank[tid] * LD + sRank[tid]];
+  if (p.all_evals && tid < G) p.all_evals[static_cast<size_t>(blockIdx.x) * G + tid] = sEval[sRank[tid]];
 
   // selected columns: smallest -> ranks 0..; largest -> ranks G-1, G-2, ...; MATRIX_SYM drops the first
   const bool smallest = p.flags & SIMAMBA_SPEC_SMALLEST;
@@ -272,7 +290,7 @@ __global__ __launch_bounds__(kEigThreads) void laplacian_eig_kernel(EigArgs p) {
     const int col = p.all_evecs ? sRank[tid] : sSel[tid];
     float best = -1.f, sgn = 1.f;
     for (int i = 0; i < G; ++i) {
-      const float v = V[i * LD + col];
+      const float v = Vt[col * LD + i];
       if (fabsf(v) > best) { best = fabsf(v); sgn = v < 0.f ? -1.f : 1.f; }
     }
     sSign[col] = sgn;
@@ -283,15 +301,15 @@ __global__ __launch_bounds__(kEigThreads) void laplacian_eig_kernel(EigArgs p) {
     for (int e = tid; e < G * G; e += kEigThreads) {
       const int i = e / G, r = e - i * G;
       const int col = sRank[r];
-      out[e] = V[i * LD + col] * sSign[col];
+      out[e] = Vt[col * LD + i] * sSign[col];
     }
   }
-  if (p.evals && tid < nsel) p.evals[static_cast<size_t>(blockIdx.x) * nsel + tid] = S[sSel[tid] * LD + sSel[tid]];
+  if (p.evals && tid < nsel) p.evals[static_cast<size_t>(blockIdx.x) * nsel + tid] = sEval[sSel[tid]];
   if (p.evecs) {
     float* out = p.evecs + static_cast<size_t>(blockIdx.x) * G * nsel;
     for (int e = tid; e < G * nsel; e += kEigThreads) {
       const int i = e / nsel, m = e - i * nsel;
-      out[e] = V[i * LD + sSel[m]] * sSign[sSel[m]];
+      out[e] = Vt[sSel[m] * LD + i] * sSign[sSel[m]];
     }
   }
   if (p.order) {
@@ -300,10 +318,10 @@ __global__ __launch_bounds__(kEigThreads) void laplacian_eig_kernel(EigArgs p) {
       const int m = e / G, i = e - m * G;
       const int col = sSel[m];
       const float sg = sSign[col];
-      const float vi = V[i * LD + col] * sg;
+      const float vi = Vt[col * LD + i] * sg;
       int rk = 0;
       for (int j = 0; j < G; ++j) {
-        const float vj = V[j * LD + col] * sg;
+        const float vj = Vt[col * LD + j] * sg;
         rk += (vj < vi) || (vj == vi && j < i);
       }
       out[m * G + rk] = i;
@@ -338,7 +356,7 @@ extern "C" size_t simamba_spectral_workspace_bytes(int B, int G) {
 // the value never changes afterwards, so this is not observable state)
 static void ensure_lds_attrs() {
   static const bool once = [] {
-    const int cap = 2 * kSpecMaxG * (kSpecMaxG + 1) * 4;
+    const int cap = 2 * kSpecMaxG * (kSpecMaxG + 1) * 4;   // knn_graph_kernel's two G x (G+1) tiles
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(laplacian_eig_kernel),
                         hipFuncAttributeMaxDynamicSharedMemorySize, cap);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(knn_graph_kernel),
@@ -387,7 +405,7 @@ extern "C" int simamba_laplacian_topk(const float* adj, float* evals, float* eve
   if (k < 0 || need > G) return SIMAMBA_E_GROUPS;
   if (B == 0) return SIMAMBA_OK;
   EigArgs a{adj, evals, evecs, order, all_evals, all_evecs, B, G, k, flags};
-  const size_t smem = sizeof(float) * 2 * G * (G + 1);
+  const size_t smem = sizeof(float) * kSpecMaxG * kEigLD;
   ensure_lds_attrs();
   hipLaunchKernelGGL(laplacian_eig_kernel, dim3(B), dim3(kEigThreads), smem, static_cast<hipStream_t>(stream), a);
   return static_cast<int>(hipGetLastError());
