@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define SIMAMBA_ABI_VERSION 2
+#define SIMAMBA_ABI_VERSION 3
 
 #define SIMAMBA_F32  0
 #define SIMAMBA_BF16 1
@@ -76,15 +76,20 @@ int         simamba_scan_num_chunks(int seqlen);
  *   x_ckpt           : (batch, dim, nchunks, dstate) fp32 or NULL.  State at the END of every
  *                      chunk; required by the backward when nchunks > 1.
  *   last_state       : (batch, dim, dstate) fp32 or NULL.
+ *   workspace        : optional scratch of >= simamba_scan_fwd_workspace_bytes(...) bytes.  When given
+ *                      and that function returned non-zero, the "one lane per channel" kernel runs
+ *                      (B_t, C_t packed to (batch, seqlen, 32) fp32 in the workspace and read through
+ *                      scalar loads); otherwise the row-scan kernel, which needs no scratch.
  *   out = (scan(u, softplus?(delta + delta_bias), A, B, C) + D*u) * silu(z)
  */
+size_t simamba_scan_fwd_workspace_bytes(int batch, int dim, int seqlen, int dstate);
 int simamba_selective_scan_fwd(const void* u, const void* delta, const float* A,
                                const void* B, const void* C, const float* D, const void* z,
                                const float* delta_bias, void* out, float* x_ckpt,
                                float* last_state, int batch, int dim, int seqlen, int dstate,
                                int io_dtype, int delta_softplus, long long z_bstride,
                                long long bc_bstride, long long bc_nstride, long long bc_tstride,
-                               void* stream);
+                               void* workspace, size_t ws_bytes, void* stream);
 
 /*
  * Selective scan backward.  Inputs as forward (+ dout, x_ckpt from the forward when

@@ -25,14 +25,15 @@ SPEC_SIGMA_MEAN = 0x20
 # name -> (restype, argtypes); mirrors include/simamba.h one to one
 _P = c_void_p
 _LL = c_longlong
-ABI_VERSION = 2
+ABI_VERSION = 3
 SIGNATURES = {
     "simamba_abi_version": (c_int, []),
     "simamba_strerror": (c_char_p, [c_int]),
     "simamba_scan_num_chunks": (c_int, [c_int]),
     "simamba_selective_scan_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                            c_int, c_int, c_int, c_int, c_int, c_int,
-                                           _LL, _LL, _LL, _LL, _P]),
+                                           _LL, _LL, _LL, _LL, _P, c_size_t, _P]),
+    "simamba_scan_fwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "simamba_selective_scan_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                            _P, _P, _P, _P, _P, _P, _P, _P,
                                            c_int, c_int, c_int, c_int, c_int, c_int,
@@ -144,3 +145,17 @@ def kernel_times():
         ms = [a.elapsed_time(b) for a, b in evs]
         out[name] = (len(ms), sum(ms) / max(len(ms), 1))
     return out
+
+
+def scan_workspace(batch, dim, seqlen, dstate, device):
+    """Scratch that opts a forward call into the one-lane-per-channel kernel (scan_fwd_seq.hip).
+
+    Off unless SIMAMBA_SEQ_FWD=1: on MI355X that kernel issues half the VALU instructions of the row-scan
+    kernel but measures the same 163 us at (256,768,128,16), so the simpler
+    kernel stays the default; the switch keeps the alternative testable.
+    """
+    import torch
+    if os.environ.get("SIMAMBA_SEQ_FWD", "0") != "1":
+        return None
+    n = load().simamba_scan_fwd_workspace_bytes(batch, dim, seqlen, dstate)
+    return torch.empty(n, device=device, dtype=torch.uint8) if n else None

@@ -138,9 +138,25 @@ static int launch_fwd(const ScanArgs& a, hipStream_t s) {
   return static_cast<int>(hipGetLastError());
 }
 
+int scan_fwd_seq_dispatch(const void* u, const void* delta, const float* A, const void* B, const void* C, const float* D,
+                          const void* z, const float* delta_bias, void* out, float* x_ckpt, float* last_state,
+                          int batch, int dim, int seqlen, int dstate, int io_dtype, int delta_softplus,
+                          long long z_bs, long long bc_bs, long long bc_ns, long long bc_ts, int vec, int nchunks128,
+                          void* workspace, hipStream_t s);
+
+// rows (batch * dim) from which one row per lane still gives every SIMD >= 1.5 waves
+constexpr long long kSeqMinRows = 98304;
+
 }  // namespace simamba
 
 using namespace simamba;
+
+extern "C" size_t simamba_scan_fwd_workspace_bytes(int batch, int dim, int seqlen, int dstate) {
+  if (batch <= 0 || dim <= 0 || seqlen <= 0 || dstate != kMaxState) return 0;
+  if (static_cast<long long>(batch) * dim < kSeqMinRows) return 0;
+  if (static_cast<long long>(batch) * dim * seqlen >= (1ll << 30)) return 0;   // kernel uses 32-bit element offsets
+  return sizeof(float) * 32 * static_cast<size_t>(batch) * seqlen;
+}
 
 extern "C" int simamba_scan_num_chunks(int seqlen) {
   if (seqlen <= 64) return 1;
@@ -155,7 +171,7 @@ extern "C" int simamba_selective_scan_fwd(const void* u, const void* delta, cons
                                           float* last_state, int batch, int dim, int seqlen, int dstate,
                                           int io_dtype, int delta_softplus, long long z_bstride,
                                           long long bc_bstride, long long bc_nstride, long long bc_tstride,
-                                          void* stream) {
+                                          void* workspace, size_t ws_bytes, void* stream) {
   if (batch < 0 || dim <= 0 || seqlen < 0 || batch > 65535) return SIMAMBA_E_SHAPE;
   if (dstate < 1 || dstate > kMaxState) return SIMAMBA_E_DSTATE;
   if (io_dtype != SIMAMBA_F32 && io_dtype != SIMAMBA_BF16) return SIMAMBA_E_DTYPE;
@@ -175,10 +191,16 @@ extern "C" int simamba_selective_scan_fwd(const void* u, const void* delta, cons
   a.bc_bs = bc_bstride; a.bc_ns = bc_nstride; a.bc_ts = bc_tstride;
   a.vec = ((seqlen * esz) % 16 == 0) && aligned16(u) && aligned16(delta) && aligned16(out) &&
           (!z || (aligned16(z) && (a.z_bs * esz) % 16 == 0));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const size_t need = simamba_scan_fwd_workspace_bytes(batch, dim, seqlen, dstate);
+  if (need && a.vec && workspace && ws_bytes >= need && aligned16(workspace) &&
+      static_cast<long long>(batch) * a.z_bs < (1ll << 31))
+    return scan_fwd_seq_dispatch(u, delta, A, B, C, D, z, delta_bias, out, x_ckpt, last_state, batch, dim, seqlen,
+                                 dstate, io_dtype, delta_softplus, a.z_bs, a.bc_bs, a.bc_ns, a.bc_ts, a.vec,
+                                 a.nchunks, workspace, s);
   // channels per workgroup: amortise the (B_t,C_t) staging, but keep >= ~3 workgroups per CU
   int passes = 4;
   while (passes > 1 && static_cast<long long>(batch) * ((dim + 16 * passes - 1) / (16 * passes)) < 768) passes >>= 1;
   a.passes = passes;
-  hipStream_t s = static_cast<hipStream_t>(stream);
   return io_dtype == SIMAMBA_F32 ? launch_fwd<float>(a, s) : launch_fwd<bf16_t>(a, s);
 }

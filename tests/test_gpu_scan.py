@@ -181,3 +181,36 @@ def test_scan_backward_full_size_against_row_subset(device):
     want.backward(t["dout"][bi:bi + 1, ds].cpu())
     for k in ("u", "delta", "z"):
         assert nerr(leaves[k].grad[bi:bi + 1, ds], sub[k].grad) < 1e-3, k
+
+
+# ---- the one-lane-per-channel forward (taken when batch*dim >= 98304 and rows are pack-aligned) ----------
+@pytest.mark.parametrize("L,dtype", [(16, torch.float32), (40, torch.float32), (132, torch.float32),
+                                     (260, torch.float32), (136, torch.bfloat16)])
+def test_scan_seq_kernel_path(L, dtype, device, monkeypatch):
+    """Same parity bar as the row-scan kernel, on a row subset (the full tensor is too slow for the CPU
+    oracle), including the chunk checkpoints it hands to the backward (L > 128) and the final state."""
+    from si_mamba_amd import _lib, selective_scan_fn
+    monkeypatch.setenv("SIMAMBA_SEQ_FWD", "1")
+    B, D, N = 128, 768, 16
+    assert _lib.load().simamba_scan_fwd_workspace_bytes(B, D, L, N) > 0     # this shape takes the seq kernel
+    inp = scan_inputs(B, D, L, N, seed=L)
+    t = {k: v.to(device) for k, v in inp.items()}
+    for k in ("u", "delta", "z", "B", "C", "dout"):
+        t[k] = t[k].to(dtype)
+    leaves = {k: t[k].clone().requires_grad_(True) for k in ("u", "delta", "z")}
+    out, last = selective_scan_fn(leaves["u"], leaves["delta"], t["A"], t["B"], t["C"], t["D"], leaves["z"],
+                                  t["delta_bias"], True, True)
+    out.backward(t["dout"])
+    tol = TOL[dtype]
+    g = torch.Generator().manual_seed(1)
+    ds = torch.randperm(D, generator=g)[:40]
+    for bi in (0, 77, 127):
+        sub = {k: t[k][bi:bi + 1, ds].float().cpu().clone().requires_grad_(True) for k in ("u", "delta", "z")}
+        want, wlast = scan_ref.selective_scan_ref(sub["u"], sub["delta"], t["A"][ds].cpu(),
+                                                  t["B"][bi:bi + 1].float().cpu(), t["C"][bi:bi + 1].float().cpu(),
+                                                  t["D"][ds].cpu(), sub["z"], t["delta_bias"][ds].cpu(), True, True)
+        want.backward(t["dout"][bi:bi + 1, ds].float().cpu())
+        assert nerr(out[bi:bi + 1, ds], want) < tol
+        assert nerr(last[bi:bi + 1, ds], wlast) < tol
+        for k in ("u", "delta", "z"):
+            assert nerr(leaves[k].grad[bi:bi + 1, ds], sub[k].grad) < tol, k
