@@ -58,9 +58,8 @@ def gather_tensor(tensor, world_size=None):
 def wrap_ddp(model, device=None, bucket_cap_mb: int = 64):
     """DDP tuned for xGMI: the 49 MB of fp32 gradients go out as ONE bucket (ring all-reduce is
     per-link bound, fewer/larger messages win), gradients alias the bucket, static graph."""
-    _, ws = get_dist_info()
-    if ws == 1:
-        return model
+    if not (dist.is_available() and dist.is_initialized()):
+        return model                      # plain single-process run: nothing to synchronise
     from torch.nn.parallel import DistributedDataParallel as DDP
     ids = None if device is None or device.type != "cuda" else [device.index]
     return DDP(model, device_ids=ids, bucket_cap_mb=bucket_cap_mb, gradient_as_bucket_view=True,

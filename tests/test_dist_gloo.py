@@ -77,4 +77,4 @@ def test_single_process_helpers_are_identity():
     t = torch.arange(3.0)
     assert torch.equal(sdist.reduce_tensor(t), t) and torch.equal(sdist.gather_tensor(t), t)
     m = nn.Linear(2, 2)
-    assert sdist.wrap_ddp(m) is m
+    assert sdist.wrap_ddp(m) is m          # no process group: left unwrapped

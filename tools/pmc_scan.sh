@@ -13,6 +13,7 @@ for ctrs in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY
   rc=$?; echo "[pmc pass $i] rc=$rc"
   if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then exit 1; fi
 done
+find gpurun_out/pmc -name "*kernel_trace.csv" -delete
 python - <<'PY'
 import csv, glob, collections
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
