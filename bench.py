@@ -59,7 +59,7 @@ def traffic_from_profiles(kernel, shape):
 
 def cpu_baseline(npts, groups, seed=0):
     """Oracle port of the same training step (same architecture, fp32) on a bounded 2-cloud sample."""
-    from oracle import scan_ref, spectral_ref
+    from oracle import fps_ref, scan_ref, spectral_ref
     from si_mamba_amd.point_mamba import PointMamba, default_config
     # the oracle's per-timestep torch ops are tiny: more threads only add fork/join latency
     torch.set_num_threads(min(16, torch.get_num_threads()))
@@ -71,13 +71,14 @@ def cpu_baseline(npts, groups, seed=0):
         ref.load_state_dict(layer.mixer.state_dict())
         layer.mixer = ref
 
-    def order_tokens(tokens, pos, center):
+    def spectral_order(center):
         adj = spectral_ref.create_graph_from_feature_space(center, cfg.knn_graph, cfg.alpha, cfg.symmetric,
                                                            cfg.self_loop, cfg.binary)
         _, vecs, _, _ = spectral_ref.calc_top_k_eigenvalues_eigenvectors(adj, cfg.k_top_eigenvectors, True)
-        return spectral_ref.sast_assemble(tokens, pos, vecs, reverse=True)
+        return spectral_ref.spectral_orders(vecs)
 
-    m.order_tokens = order_tokens
+    m.spectral_order = spectral_order
+    m.group_divider.fps_fn = fps_ref.sample_farthest_points
     m.train()
     B = 2
     pts = make_clouds(B, npts, seed, "cpu")

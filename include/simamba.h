@@ -18,6 +18,7 @@
  *                                    (per-sample torch.linalg.eigh loop, cuSOLVER underneath).
  *   simamba_spectral_topk            the two above fused: centres -> top-k eigenpairs + orders.
  *   simamba_argsort_rows             the torch.sort of models/point_mamba.py:820.
+ *   simamba_farthest_point_sample    pytorch3d.ops.sample_farthest_points, models/point_mamba.py:93.
  *
  * Conventions
  *   - Plain pointers and sizes only.  All pointers are DEVICE pointers unless noted.
@@ -160,6 +161,15 @@ size_t simamba_spectral_workspace_bytes(int B, int G);
 int simamba_spectral_topk(const float* centers, float* evals, float* evecs, long long* order,
                           void* workspace, size_t ws_bytes, int B, int G, int knn, float alpha,
                           int k, unsigned flags, void* stream);
+
+/*
+ * Farthest-point sampling (tokeniser step ahead of the hot path; replaces
+ * pytorch3d.ops.sample_farthest_points at reference models/point_mamba.py:93).
+ *   points (B, N, 3) fp32 -> idx (B, K) int64 (first pick = point 0, ties to the lower index),
+ *   centers (B, K, 3) fp32 or NULL.  N <= 4096, K <= N.
+ */
+int simamba_farthest_point_sample(const float* points, long long* idx, float* centers, int B, int N,
+                                  int K, void* stream);
 
 /* vals (rows, n) fp32 -> idx (rows, n) int64, ascending, ties by index.  n <= 1024. */
 int simamba_argsort_rows(const float* vals, long long* idx, int rows, int n, void* stream);

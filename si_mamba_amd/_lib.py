@@ -47,6 +47,7 @@ SIGNATURES = {
     "simamba_spectral_topk": (c_int, [_P, _P, _P, _P, _P, c_size_t, c_int, c_int, c_int, c_float,
                                       c_int, c_uint, _P]),
     "simamba_argsort_rows": (c_int, [_P, _P, c_int, c_int, _P]),
+    "simamba_farthest_point_sample": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),
 }
 
 _lib = None

@@ -8,8 +8,8 @@ reference state_dict loads unchanged.  What runs on the HIP kernels: the spectra
 
 ``Group`` (farthest-point sampling + k-NN grouping) and ``Encoder`` (mini-PointNet) sit BEFORE the
 hot path ("next" row 1).  The reference gets FPS / k-NN from pytorch3d CUDA ops
-(:93, :96), which are absent here; ``Group`` below is a plain-torch stand-in used by the
-benchmark / test harness only, and is not part of the graded path.
+(:93, :96), which are absent here: FPS is the HIP kernel of csrc/fps.hip, the k-NN grouping and the
+encoder are plain torch (cdist/topk, GEMMs).
 """
 from __future__ import annotations
 
@@ -18,37 +18,27 @@ from types import SimpleNamespace
 import torch
 import torch.nn as nn
 
-from . import spectral
+from . import grouping, spectral
 from .block import MixerModel
 
 
-def farthest_point_sample(xyz, K):
-    """Iterative FPS started at index 0 (pytorch3d.sample_farthest_points default, :93)."""
-    B, N, _ = xyz.shape
-    idx = torch.zeros(B, K, dtype=torch.long, device=xyz.device)
-    mind = torch.full((B, N), float("inf"), device=xyz.device, dtype=xyz.dtype)
-    cur = torch.zeros(B, dtype=torch.long, device=xyz.device)
-    ar = torch.arange(B, device=xyz.device)
-    for i in range(K):
-        idx[:, i] = cur
-        d = ((xyz - xyz[ar, cur][:, None, :]) ** 2).sum(-1)
-        mind = torch.minimum(mind, d)
-        cur = mind.argmax(dim=1)
-    return idx
-
-
 class Group(nn.Module):
-    """(B,N,3) -> neighborhood (B,G,M,3) centred, center (B,G,3), neighborhood_org; reference :76-111."""
+    """(B,N,3) -> neighborhood (B,G,M,3) centred, center (B,G,3), neighborhood_org; reference :76-111.
+
+    Farthest-point sampling runs on the HIP kernel (grouping.sample_farthest_points, the counterpart of
+    the pytorch3d call at :93); the k-NN grouping (:96) is cdist + topk in torch.  ``fps_fn`` can be
+    swapped (bench.py's CPU baseline plugs the oracle in).
+    """
 
     def __init__(self, num_group, group_size):
         super().__init__()
         self.num_group = num_group
         self.group_size = group_size
+        self.fps_fn = grouping.sample_farthest_points
 
     @torch.no_grad()
     def _indices(self, xyz):
-        cidx = farthest_point_sample(xyz, self.num_group)
-        center = torch.gather(xyz, 1, cidx.unsqueeze(-1).expand(-1, -1, 3))
+        center, _ = self.fps_fn(xyz, self.num_group)
         d = torch.cdist(center, xyz)
         nn_idx = d.topk(self.group_size, dim=-1, largest=False, sorted=False)[1]
         return center, nn_idx
@@ -73,11 +63,20 @@ class Encoder(nn.Module):
                                          nn.Conv1d(512, self.encoder_channel, 1))
 
     def forward(self, point_groups):
+        """(B, G, n, 3) -> (B, G, C).  The four 1x1 convolutions are plain GEMMs on the (B*G*n, C)
+        token-major view (same Conv1d / BatchNorm1d parameters, same arithmetic); this avoids the
+        NCHW<->NHWC transposes MIOpen inserts around its implicit-GEMM kernels."""
         bs, g, n, _ = point_groups.shape
-        f = self.first_conv(point_groups.reshape(bs * g, n, 3).transpose(2, 1))
-        fg = torch.max(f, dim=2, keepdim=True)[0]
-        f = self.second_conv(torch.cat([fg.expand(-1, -1, n), f], dim=1))
-        return torch.max(f, dim=2, keepdim=False)[0].reshape(bs, g, self.encoder_channel)
+        c1, bn1, _, c2 = self.first_conv
+        c3, bn2, _, c4 = self.second_conv
+        x = point_groups.reshape(bs * g * n, 3)
+        x = torch.relu(bn1(torch.nn.functional.linear(x, c1.weight.squeeze(-1), c1.bias)))
+        f = torch.nn.functional.linear(x, c2.weight.squeeze(-1), c2.bias).view(bs * g, n, 256)
+        fg = f.max(dim=1, keepdim=True)[0]
+        x = torch.cat([fg.expand(-1, n, -1), f], dim=2).reshape(bs * g * n, 512)
+        x = torch.relu(bn2(torch.nn.functional.linear(x, c3.weight.squeeze(-1), c3.bias)))
+        f = torch.nn.functional.linear(x, c4.weight.squeeze(-1), c4.bias).view(bs * g, n, self.encoder_channel)
+        return f.max(dim=1)[0].reshape(bs, g, self.encoder_channel)
 
 
 def default_config(**over):
@@ -128,25 +127,43 @@ class PointMamba(nn.Module):
         if self.method != "SAST":
             raise NotImplementedError("only the canonical SAST route is built (SURVEY.md headline 3)")
 
+    def _side_stream(self, device):
+        st = getattr(self, "_spectral_stream", None)
+        if st is None or st.device != device:
+            st = torch.cuda.Stream(device=device)
+            self._spectral_stream = st
+        return st
+
     def get_loss_acc(self, ret, gt):
         loss = self.loss_ce(ret, gt.long())
         pred = ret.argmax(-1)
         acc = (pred == gt).sum() / float(gt.size(0))
         return loss, acc * 100
 
-    def order_tokens(self, tokens, pos, center):
-        """reference :872-898 + :982-989: spectral ordering of (tokens, pos)."""
-        _, _, order = spectral.spectral_order(center, self.knn_graph, self.alpha, self.k_top_eigenvectors,
-                                              smallest=self.smallest, symmetric=self.symmetric,
-                                              self_loop=self.self_loop, binary=self.binary,
-                                              matrix=self.matrix)
-        return spectral.sast_gather(tokens, pos, order, reverse=self.reverse)
+    def spectral_order(self, center):
+        return spectral.spectral_order(center, self.knn_graph, self.alpha, self.k_top_eigenvectors,
+                                       smallest=self.smallest, symmetric=self.symmetric,
+                                       self_loop=self.self_loop, binary=self.binary, matrix=self.matrix)[2]
 
     def forward(self, pts, gt=None):
         neighborhood, center, _ = self.group_divider(pts)
+        # The eigen-ordering depends only on the centres and is latency-bound on B of the 256 CUs: run it
+        # on a side HIP stream underneath the (MFMA-bound) patch encoder, join before the gather.
+        if center.is_cuda:
+            main = torch.cuda.current_stream(center.device)
+            side = self._side_stream(center.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                order = self.spectral_order(center)
+            center.record_stream(side)
+        else:
+            order = self.spectral_order(center)
         tokens = self.encoder(neighborhood)
         pos = self.pos_embed(center)
-        x, pos = self.order_tokens(tokens, pos, center)
+        if center.is_cuda:
+            main.wait_stream(side)
+            order.record_stream(main)
+        x, pos = spectral.sast_gather(tokens, pos, order, reverse=self.reverse)
         x = self.drop_out(x)
         x = self.blocks(x, pos)
         x = self.norm(x)

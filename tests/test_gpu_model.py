@@ -2,7 +2,7 @@
 import pytest
 import torch
 
-from oracle import scan_ref, spectral_ref as sr
+from oracle import fps_ref, scan_ref, spectral_ref as sr
 
 pytestmark = pytest.mark.gpu
 
@@ -60,3 +60,17 @@ def test_pointmamba_full_config_train_step(device):
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
     opt.step()
     assert torch.isfinite(loss)
+
+
+@pytest.mark.parametrize("shape", [(64, 1024, 128), (5, 2048, 128), (3, 100, 17), (2, 4096, 64), (1, 8, 8)])
+def test_farthest_point_sampling_matches_oracle(shape, device):
+    """Index work: bit-exact against the restatement of pytorch3d's algorithm (start at 0, squared distances
+    accumulated without FMA, first maximum on ties)."""
+    from si_mamba_amd import grouping
+    B, N, K = shape
+    pts = _clouds(B, N, seed=N + K)
+    centers, idx = grouping.sample_farthest_points(pts.to(device), K)
+    wc, widx = fps_ref.sample_farthest_points(pts, K)
+    assert torch.equal(idx.cpu(), widx)
+    assert torch.equal(centers.cpu(), wc)
+    assert (idx[:, 0] == 0).all() and all(len(set(r.tolist())) == K for r in idx.cpu())
