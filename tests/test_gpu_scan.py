@@ -214,3 +214,26 @@ def test_scan_seq_kernel_path(L, dtype, device, monkeypatch):
         assert nerr(last[bi:bi + 1, ds], wlast) < tol
         for k in ("u", "delta", "z"):
             assert nerr(leaves[k].grad[bi:bi + 1, ds], sub[k].grad) < tol, k
+
+
+def test_scan_strided_operands(device):
+    """z as a batch-strided half of a (B, 2D, L) tensor and B/C as token-major views of a (B, L, R+2N)
+    tensor -- the layouts the mixer produces -- are read in place and match the contiguous call."""
+    from si_mamba_amd import selective_scan_fn
+    inp = scan_inputs(3, 48, 160, 16, seed=21)
+    t = {k: v.to(device) for k, v in inp.items()}
+    xz = torch.randn(3, 96, 160, device=device)
+    xz[:, 48:] = t["z"]
+    x_dbl = torch.randn(3, 160, 8 + 32, device=device)
+    x_dbl[:, :, 8:24] = t["B"].transpose(1, 2)
+    x_dbl[:, :, 24:] = t["C"].transpose(1, 2)
+    zs = xz[:, 48:].requires_grad_(False)
+    Bs, Cs = x_dbl[:, :, 8:24].transpose(1, 2), x_dbl[:, :, 24:].transpose(1, 2)
+    assert not zs.is_contiguous() and not Bs.is_contiguous()
+    u = t["u"].clone().requires_grad_(True)
+    u2 = t["u"].clone().requires_grad_(True)
+    a = selective_scan_fn(u, t["delta"], t["A"], Bs, Cs, t["D"], zs, t["delta_bias"], True)
+    b = selective_scan_fn(u2, t["delta"], t["A"], t["B"], t["C"], t["D"], t["z"], t["delta_bias"], True)
+    assert torch.equal(a, b)
+    a.backward(t["dout"]); b.backward(t["dout"])
+    torch.testing.assert_close(u.grad, u2.grad, rtol=1e-5, atol=1e-5)
