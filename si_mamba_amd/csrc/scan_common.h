@@ -110,6 +110,12 @@ __device__ __forceinline__ void load_A_row(const float* __restrict__ Arow, int N
   }
 }
 
+// LDS image of a (state, time) tile row: 16-byte quads, with the quads of the upper half of a 128-step row
+// swapped pairwise (q ^ 1 for q >= 16).  A lane reads quads 2*lane16 and 2*lane16 + 1; unswizzled, lanes l
+// and l + 8 would sit 256 B = one full 64-bank sweep apart and collide on every ds_read_b128 (measured:
+// SQ_LDS_BANK_CONFLICT = 49 % of SQ_LDS_IDX_ACTIVE); swizzled, the 16 lanes of a row cover 16 distinct quads.
+__device__ __forceinline__ int bc_quad(int q) { return q ^ ((q >> 4) & 1); }
+
 // stage the chunk's B and C tiles (dstate x LC) of one batch sample into LDS, zero padded.
 // The global side is read through (state, time) strides: time-major (B,N,L) tensors are walked with
 // consecutive lanes on consecutive t, token-major ones (x_proj output, state stride 1) on consecutive n.
@@ -132,8 +138,9 @@ __device__ __forceinline__ void stage_bc(const T* __restrict__ Bg, const T* __re
       vb = to_f32<T>(Bg[o]);
       vc = to_f32<T>(Cg[o]);
     }
-    sB[n * LDP + t] = vb;
-    sC[n * LDP + t] = vc;
+    const int slot = n * LDP + bc_quad(t >> 2) * 4 + (t & 3);
+    sB[slot] = vb;
+    sC[slot] = vc;
   }
 }
 

@@ -69,13 +69,14 @@ __global__ __launch_bounds__(kScanThreads) void scan_fwd_kernel(ScanArgs p) {
       for (int n = 0; n < kMaxState; ++n) {
         if (n < N) {
           const float A2n = A2[n];
-          const float* bp = sB + n * LDP + lane16 * kItems;
-          const float* cp = sC + n * LDP + lane16 * kItems;
+          const float* bp = sB + n * LDP;
+          const float* cp = sC + n * LDP;
           float a[kItems], bb[kItems], cc[kItems];
 #pragma unroll
           for (int i = 0; i < kItems; i += 4) {
-            float4 vb = *reinterpret_cast<const float4*>(bp + i);
-            float4 vc = *reinterpret_cast<const float4*>(cp + i);
+            const int qo = bc_quad((lane16 * kItems + i) >> 2) * 4;
+            float4 vb = *reinterpret_cast<const float4*>(bp + qo);
+            float4 vc = *reinterpret_cast<const float4*>(cp + qo);
             bb[i] = vb.x; bb[i + 1] = vb.y; bb[i + 2] = vb.z; bb[i + 3] = vb.w;
             cc[i] = vc.x; cc[i + 1] = vc.y; cc[i + 2] = vc.z; cc[i + 3] = vc.w;
           }
