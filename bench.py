@@ -222,7 +222,7 @@ def main():
             out["roofline"] = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(ach / HBM_PEAK_GBS, 4),
                                "traffic": traffic_from_profiles("scan_fwd", (args.batch, D, L, N)) if s == 4 else None,
-                               "kernel": f"scan_fwd_kernel<{'float' if s == 4 else 'bf16'},8>",
+                               "kernel": f"scan_fwd_kernel<{'float' if s == 4 else 'bf16'},{16 if L >= 768 else 8}>",
                                "shape_BDLN": [args.batch, D, L, N], "algorithmic_bytes": nbytes,
                                "launches": n, "mean_ms": round(ms, 4)}
             out["kernels"] = {k: {"launches": v[0], "mean_ms": round(v[1], 4)} for k, v in ktimes.items()}

@@ -162,7 +162,7 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_bwd_kernel(ScanArgs p) {
           float a[kItems], bw[kItems], cc[kItems], hp[kItems];
 #pragma unroll
           for (int i = 0; i < kItems; i += 4) {
-            const int qo = bc_quad((lane16 * kItems + i) >> 2) * 4;
+            const int qo = bc_quad<kItems>((lane16 * kItems + i) >> 2) * 4;
             float4 vb = *reinterpret_cast<const float4*>(bp + qo);
             float4 vc = *reinterpret_cast<const float4*>(cp + qo);
             bw[i] = vb.x; bw[i + 1] = vb.y; bw[i + 2] = vb.z; bw[i + 3] = vb.w;

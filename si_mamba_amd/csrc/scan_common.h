@@ -44,6 +44,7 @@ struct ScanArgs {
   int batch, dim, seqlen, dstate;
   int nchunks;
   int passes;     // R: channel passes per workgroup (tile = 16 * R channels)
+  int long_items; // forward: 16 steps per lane for L > 128
   int vec;        // 16-byte vector access allowed
   int softplus;
   long long z_bs, dz_bs;            // batch strides (elements) of z / dz
@@ -110,11 +111,12 @@ __device__ __forceinline__ void load_A_row(const float* __restrict__ Arow, int N
   }
 }
 
-// LDS image of a (state, time) tile row: 16-byte quads, with the quads of the upper half of a 128-step row
-// swapped pairwise (q ^ 1 for q >= 16).  A lane reads quads 2*lane16 and 2*lane16 + 1; unswizzled, lanes l
-// and l + 8 would sit 256 B = one full 64-bank sweep apart and collide on every ds_read_b128 (measured:
-// SQ_LDS_BANK_CONFLICT = 49 % of SQ_LDS_IDX_ACTIVE); swizzled, the 16 lanes of a row cover 16 distinct quads.
-__device__ __forceinline__ int bc_quad(int q) { return q ^ ((q >> 4) & 1); }
+// LDS image of a (state, time) tile row: 16-byte quads, XOR-swizzled by the 64-byte-group index.  A lane reads
+// the kItems/4 consecutive quads of its time segment, one per ds_read_b128; unswizzled, lanes 64 bytes x 4
+// apart would share bank quads on every read (measured at kItems = 8: SQ_LDS_BANK_CONFLICT = 49 % of
+// SQ_LDS_IDX_ACTIVE); with q ^ ((q >> 4) & (kItems/4 - 1)) the 16 lanes of a row cover 16 distinct quads.
+template <int kItems>
+__device__ __forceinline__ int bc_quad(int q) { return q ^ ((q >> 4) & (kItems / 4 - 1)); }
 
 // stage the chunk's B and C tiles (dstate x LC) of one batch sample into LDS, zero padded.
 // The global side is read through (state, time) strides: time-major (B,N,L) tensors are walked with
@@ -138,7 +140,7 @@ __device__ __forceinline__ void stage_bc(const T* __restrict__ Bg, const T* __re
       vb = to_f32<T>(Bg[o]);
       vc = to_f32<T>(Cg[o]);
     }
-    const int slot = n * LDP + bc_quad(t >> 2) * 4 + (t & 3);
+    const int slot = n * LDP + bc_quad<LC / 16>(t >> 2) * 4 + (t & 3);
     sB[slot] = vb;
     sC[slot] = vc;
   }
