@@ -161,7 +161,7 @@ def main():
     cfg = default_config(num_group=args.groups)             # cfgs/finetune_scan_hardest.yaml model block
     model = PointMamba(cfg).to(device).train()
     ddp = sdist.wrap_ddp(model, device)
-    opt = torch.optim.AdamW(model.parameters(), lr=5e-4, weight_decay=0.05)
+    opt = torch.optim.AdamW(model.parameters(), lr=5e-4, weight_decay=0.05, fused=True)
     pts = make_clouds(args.batch, args.npoints, seed=rank, device=device)
     gt = torch.randint(0, cfg.cls_dim, (args.batch,), generator=torch.Generator().manual_seed(rank)).to(device)
     amp = torch.autocast("cuda", dtype=torch.bfloat16, enabled=(args.dtype == "bf16"))
