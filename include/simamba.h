@@ -12,6 +12,7 @@
  *                                    at models/point_mamba.py:162.
  *   simamba_causal_conv1d_fwd/bwd    causal_conv1d_cuda.causal_conv1d_fwd/bwd of causal-conv1d,
  *                                    same call site (inside the mixer).
+ *   simamba_add_layer_norm_fwd/bwd   the Add -> LayerNorm of models/block.py:56-60 (torch ops there).
  *   simamba_knn_graph                models/point_mamba.py:620-661 and :664-715
  *                                    (create_graph_from_centers / ..._feature_space_...).
  *   simamba_laplacian_topk           models/point_mamba.py:717-761 and :764-814
@@ -124,6 +125,33 @@ int simamba_causal_conv1d_bwd(const void* x, const float* w, const float* bias,
                               const void* dout, void* dx, float* dw, float* dbias,
                               int batch, int dim, int seqlen, int width, int silu,
                               int io_dtype, long long x_bstride, long long dx_bstride, void* stream);
+
+/*
+ * Fused (DropPath-scaled) residual add + LayerNorm: the "Add -> LayerNorm" half of the reference's
+ * Block.forward (models/block.py:56-60) and the final norm of MixerModel (models/point_mamba.py:257-258).
+ *   hidden        : (batch, rows_per_batch, dim) hidden_dtype
+ *   residual      : same shape fp32, or NULL (first block: residual_out = hidden, not written when
+ *                   residual_out is NULL)
+ *   rowscale      : (batch) fp32 or NULL -- DropPath keep-mask / keep-prob per sample, applied to hidden
+ *                   only when residual != NULL (the reference does not drop the first block's input)
+ *   residual_out  : fp32 ; normed : out_dtype ; mean, rstd : (batch * rows_per_batch) fp32
+ *   residual_out = hidden * rowscale + residual ;  normed = LayerNorm(residual_out; weight, bias, eps)
+ * Backward: dresidual (fp32, gradient w.r.t. `residual`) = LN'(dnormed) + dresidual_out ;
+ *   dhidden (hidden_dtype) = dresidual * rowscale ; either may be NULL (not both).
+ *   dwb_partial : (simamba_add_layer_norm_grid(batch, rows_per_batch), 2, dim) fp32 -- per-workgroup partial
+ *   sums of (dweight, dbias); the caller reduces over the first axis.
+ * dim % 4 == 0, dim <= 2048.
+ */
+int simamba_add_layer_norm_grid(int batch, int rows_per_batch);
+int simamba_add_layer_norm_fwd(const void* hidden, const float* residual, const float* rowscale,
+                               const float* weight, const float* bias, float* residual_out,
+                               void* normed, float* mean, float* rstd, int batch, int rows_per_batch,
+                               int dim, float eps, int hidden_dtype, int out_dtype, void* stream);
+int simamba_add_layer_norm_bwd(const void* dnormed, const float* dresidual_out,
+                               const float* residual_out, const float* mean, const float* rstd,
+                               const float* weight, const float* rowscale, float* dresidual,
+                               void* dhidden, float* dwb_partial, int batch, int rows_per_batch,
+                               int dim, int hidden_dtype, int out_dtype, void* stream);
 
 /* ---- spectral ordering ---------------------------------------------------------------- */
 #define SIMAMBA_SPEC_SYMMETRIC   0x01u  /* also write A[j,i] for every kNN edge (i,j)          */

@@ -41,6 +41,11 @@ SIGNATURES = {
     "simamba_causal_conv1d_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _LL, _P]),
     "simamba_causal_conv1d_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P,
                                           c_int, c_int, c_int, c_int, c_int, c_int, _LL, _LL, _P]),
+    "simamba_add_layer_norm_grid": (c_int, [c_int, c_int]),
+    "simamba_add_layer_norm_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float,
+                                           c_int, c_int, _P]),
+    "simamba_add_layer_norm_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int,
+                                           c_int, c_int, _P]),
     "simamba_knn_graph": (c_int, [_P, _P, _P, c_size_t, c_int, c_int, c_int, c_int, c_float, c_uint, _P]),
     "simamba_laplacian_topk": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_uint, _P]),
     "simamba_spectral_workspace_bytes": (c_size_t, [c_int, c_int]),

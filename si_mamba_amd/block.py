@@ -20,6 +20,7 @@ import torch
 import torch.nn as nn
 from torch import Tensor
 
+from .add_norm import add_layer_norm_fn
 from .mamba_simple import Mamba
 
 
@@ -31,14 +32,19 @@ class DropPath(nn.Module):
         self.drop_prob = drop_prob
         self.scale_by_keep = scale_by_keep
 
-    def forward(self, x):
+    def rowscale(self, x):
+        """Per-sample factor (B,) this layer would multiply x by, or None when it is the identity."""
         if self.drop_prob == 0.0 or not self.training:
-            return x
+            return None
         keep = 1.0 - self.drop_prob
-        mask = x.new_empty((x.shape[0],) + (1,) * (x.dim() - 1)).bernoulli_(keep)
+        mask = torch.empty(x.shape[0], device=x.device, dtype=torch.float32).bernoulli_(keep)
         if keep > 0.0 and self.scale_by_keep:
             mask.div_(keep)
-        return x * mask
+        return mask
+
+    def forward(self, x):
+        mask = self.rowscale(x)
+        return x if mask is None else x * mask.to(x.dtype).view((-1,) + (1,) * (x.dim() - 1))
 
 
 class Block(nn.Module):
@@ -55,11 +61,19 @@ class Block(nn.Module):
         self.drop_path = DropPath(drop_path) if drop_path > 0. else nn.Identity()
 
     def forward(self, hidden_states: Tensor, residual: Optional[Tensor] = None, inference_params=None):
-        """hidden_states = Mixer(LN(residual)); returns (hidden_states, residual)."""
-        residual = (self.drop_path(hidden_states) + residual) if residual is not None else hidden_states
-        hidden_states = self.norm(residual.to(dtype=self.norm.weight.dtype))
-        if self.residual_in_fp32:
-            residual = residual.to(torch.float32)
+        """hidden_states = Mixer(LN(residual)); returns (hidden_states, residual).
+
+        Add (+ DropPath) + LayerNorm run as one HIP pass each way (add_norm.py) for LayerNorm blocks on the
+        GPU; the composed torch form below is the reference's own and serves any other norm / device."""
+        if hidden_states.is_cuda and type(self.norm) is nn.LayerNorm and hidden_states.dim() == 3:
+            scale = self.drop_path.rowscale(hidden_states) if isinstance(self.drop_path, DropPath) else None
+            hidden_states, residual = add_layer_norm_fn(hidden_states, residual, self.norm.weight, self.norm.bias,
+                                                        self.norm.eps, rowscale=scale)
+        else:
+            residual = (self.drop_path(hidden_states) + residual) if residual is not None else hidden_states
+            hidden_states = self.norm(residual.to(dtype=self.norm.weight.dtype))
+            if self.residual_in_fp32:
+                residual = residual.to(torch.float32)
         hidden_states = self.mixer(hidden_states, inference_params=inference_params)
         return hidden_states, residual
 
@@ -127,5 +141,8 @@ class MixerModel(nn.Module):
         for layer in self.layers:
             hidden_states, residual = layer(hidden_states, residual, inference_params=inference_params)
             hidden_states = self.drop_out_in_block(hidden_states)
+        if hidden_states.is_cuda and type(self.norm_f) is nn.LayerNorm and hidden_states.dim() == 3:
+            return add_layer_norm_fn(hidden_states, residual, self.norm_f.weight, self.norm_f.bias,
+                                     self.norm_f.eps)[0]
         residual = (hidden_states + residual) if residual is not None else hidden_states
         return self.norm_f(residual.to(dtype=self.norm_f.weight.dtype))
