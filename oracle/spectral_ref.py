@@ -172,3 +172,29 @@ def sast_index_map(orders, reverse=True):
     if reverse:
         idx = torch.cat((idx, idx.flip(1)), 1)
     return idx
+
+
+def hlt_order_and_assemble(tokens, pos, center, vecs, k, rand=None):
+    """reference :1059-1112 (method == "HLT", reverse == True), restated slice by slice -- including the
+    reference's overlapping block writes: forward block i lands in output block i+1 (i >= 1) and is then
+    overwritten by nothing / overwrites the previous reverse block, so the result is
+    [fwd0, rev0, fwd1, fwd2, ..., fwd_{nd-1}, rev_{nd-1}, zeros...].  ``rand`` replaces torch.rand (:1062)."""
+    integers = multilevel_travers(vecs, k).to(tokens.dtype)
+    if rand is not None:
+        integers = integers + rand
+    order = torch.argsort(integers, dim=1, stable=True)
+    st = torch.gather(tokens, 1, order.unsqueeze(-1).expand(-1, -1, tokens.shape[-1]))
+    sp = torch.gather(pos, 1, order.unsqueeze(-1).expand(-1, -1, pos.shape[-1]))
+    sc = torch.gather(center, 1, order.unsqueeze(-1).expand(-1, -1, 3))
+    ng = 2 ** k
+    nd = int(sp.shape[1] / ng)
+    out_t = torch.zeros(sp.shape[0], sp.shape[1] * 2, st.shape[2])
+    out_p = torch.zeros(sp.shape[0], sp.shape[1] * 2, sp.shape[2])
+    out_c = torch.zeros(sp.shape[0], sp.shape[1] * 2, 3)
+    for i in range(nd):
+        src = slice(i * ng, (i + 1) * ng)
+        dst = slice(i * ng, (i + 1) * ng) if i == 0 else slice((i + 1) * ng, (i + 2) * ng)
+        out_t[:, dst], out_p[:, dst], out_c[:, dst] = st[:, src], sp[:, src], sc[:, src]
+        rdst = slice((i + 1) * ng, (i + 2) * ng) if i == 0 else slice((i + 2) * ng, (i + 3) * ng)
+        out_t[:, rdst], out_p[:, rdst], out_c[:, rdst] = st[:, src].flip(1), sp[:, src].flip(1), sc[:, src].flip(1)
+    return out_t, out_p, out_c, order

@@ -164,6 +164,50 @@ def sast_gather(tokens, pos, order, reverse=True):
             torch.gather(pos, 1, ex.expand(-1, -1, pos.shape[-1])))
 
 
+def hlt_index_map(G, k, device=None):
+    """Source position (into the code-sorted sequence of G patches) of each of the 2G output slots of the
+    reference's HLT assembly (:1075-1112, reverse == True), -1 where the reference leaves zeros.
+
+    The reference writes block i (2^k patches) forward into output block i+1 (block 0 for i == 0) and flipped
+    into block i+2 (block 1 for i == 0); later writes overwrite earlier ones.  Replaying those assignments on
+    an index vector gives the same result as its slice assignments, in one gather.
+    """
+    ng = 2 ** k
+    nd = G // ng
+    idx = torch.full((2 * G,), -1, dtype=torch.int64)
+    for i in range(nd):
+        src = torch.arange(i * ng, (i + 1) * ng)
+        d0 = i * ng if i == 0 else (i + 1) * ng
+        r0 = (i + 1) * ng if i == 0 else (i + 2) * ng
+        if d0 + ng <= 2 * G:
+            idx[d0:d0 + ng] = src
+        if r0 + ng <= 2 * G:
+            idx[r0:r0 + ng] = src.flip(0)
+    return idx if device is None else idx.to(device)
+
+
+def hlt_assemble(tokens, pos, center, top_k_eigenvectors, k, rand=None):
+    """HLT token order of reference :1059-1112: bit-code traversal (multilevel_travers) + random tie-break
+    (``rand``: (B, G) in [0,1), the reference's torch.rand at :1062; None = no tie-break) -> argsort -> the
+    block assembly above.  Returns (tokens (B,2G,C), pos (B,2G,C), center (B,2G,3), order (B,G))."""
+    codes = multilevel_travers(top_k_eigenvectors, k).to(torch.float32)
+    if codes.dim() == 1:
+        codes = codes.unsqueeze(0)
+    if rand is not None:
+        codes = codes + rand
+    order = argsort_rows(codes)
+    G = order.shape[1]
+    slot = hlt_index_map(G, k, order.device)
+    valid = (slot >= 0)
+    src = torch.gather(order, 1, slot.clamp_min(0).unsqueeze(0).expand(order.shape[0], -1))     # (B, 2G)
+
+    def pick(x):
+        out = torch.gather(x, 1, src.unsqueeze(-1).expand(-1, -1, x.shape[-1]))
+        return out * valid.to(x.dtype)[None, :, None]
+
+    return pick(tokens), pick(pos), pick(center), order
+
+
 def bind_to(cls):
     """Monkey-patch the spectral methods of a reference-style PointMamba class with these kernels."""
     def _m(fn):

@@ -136,3 +136,21 @@ def test_multilevel_travers_matches_oracle(device):
     from si_mamba_amd import spectral
     v = torch.randn(3, 64, 6)
     assert torch.equal(spectral.multilevel_travers(v.to(device), 4).cpu(), sr.multilevel_travers(v, 4))
+
+
+def test_hlt_assembly_matches_reference_restated(device):
+    """HLT route (reference :1059-1112): codes -> argsort (random tie-break supplied) -> block assembly with the
+    reference's overlapping writes.  Index work: bit-exact given the same eigenvectors."""
+    from si_mamba_amd import spectral
+    g = torch.Generator().manual_seed(3)
+    B, G, k = 4, 128, 4
+    vecs = torch.randn(B, G, k, generator=g)
+    tokens, pos, center = torch.randn(B, G, 32, generator=g), torch.randn(B, G, 32, generator=g), torch.randn(B, G, 3, generator=g)
+    rand = torch.rand(B, G, generator=g)
+    for r in (None, rand):
+        wt, wp, wc, worder = sr.hlt_order_and_assemble(tokens, pos, center, vecs, k, r)
+        gt, gp, gc, gorder = spectral.hlt_assemble(tokens.to(device), pos.to(device), center.to(device),
+                                                   vecs.to(device), k, None if r is None else r.to(device))
+        assert torch.equal(gorder.cpu(), worder)
+        assert torch.equal(gt.cpu(), wt) and torch.equal(gp.cpu(), wp) and torch.equal(gc.cpu(), wc)
+    assert gt.shape == (B, 2 * G, 32) and (gt[:, 10 * 16:] == 0).all()      # the reference's unwritten tail

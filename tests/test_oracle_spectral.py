@@ -63,3 +63,20 @@ def test_multilevel_travers_codes():
     v = torch.tensor([[[0.1, -1.0], [0.5, 1.0], [-0.3, 0.2], [0.9, -0.4]]])
     codes = sr.multilevel_travers(v, 2)
     assert codes.tolist() == [[0, 3, 1, 2]]
+
+
+def test_hlt_assembly_overlapping_writes_as_index_map():
+    """The reference's HLT block assembly (:1075-1112) overwrites blocks; its net effect is the index map the
+    product uses (si_mamba_amd.spectral.hlt_index_map is pure index arithmetic, callable without a GPU)."""
+    from si_mamba_amd.spectral import hlt_index_map
+    g = torch.Generator().manual_seed(0)
+    B, G, k = 2, 64, 3
+    tokens, pos, center = torch.randn(B, G, 5, generator=g), torch.randn(B, G, 5, generator=g), torch.randn(B, G, 3, generator=g)
+    vecs = torch.randn(B, G, k, generator=g)
+    out_t, out_p, out_c, order = sr.hlt_order_and_assemble(tokens, pos, center, vecs, k, torch.rand(B, G, generator=g))
+    slot = hlt_index_map(G, k)
+    st = torch.gather(tokens, 1, order.unsqueeze(-1).expand(-1, -1, 5))
+    want = torch.where((slot >= 0)[None, :, None], st[:, slot.clamp_min(0)], torch.zeros(()))
+    assert torch.equal(out_t, want)
+    nd, ng = G // 2 ** k, 2 ** k
+    assert (slot[(nd + 2) * ng:] == -1).all() and (slot[:ng] == torch.arange(ng)).all()
