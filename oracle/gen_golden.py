@@ -24,27 +24,11 @@ import numpy as np
 import torch
 
 from oracle import scan_ref, spectral_ref
+from si_mamba_amd.synthetic import scan_inputs, unit_ball_centers  # noqa: F401  (re-exported for the tests)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "tests", "golden")
 REF_LOG = "/root/reference/logs/finetuned_hardest.log"
-
-
-def scan_inputs(batch, dim, L, N, seed, with_z=True, with_D=True, with_bias=True):
-    """SURVEY.md section 8d synthetic recipe."""
-    g = torch.Generator().manual_seed(seed)
-    u = torch.randn(batch, dim, L, generator=g)
-    z = torch.randn(batch, dim, L, generator=g) if with_z else None
-    delta = 0.5 * torch.randn(batch, dim, L, generator=g)
-    dt = torch.exp(torch.rand(dim, generator=g) * (math.log(0.1) - math.log(0.001)) + math.log(0.001))
-    bias = (dt + torch.log(-torch.expm1(-dt))) if with_bias else None
-    A = -torch.exp(torch.log(torch.arange(1, N + 1, dtype=torch.float32))[None, :].repeat(dim, 1)
-                   + 0.1 * torch.randn(dim, N, generator=g))
-    Bm = torch.randn(batch, N, L, generator=g)
-    Cm = torch.randn(batch, N, L, generator=g)
-    D = (1.0 + 0.1 * torch.randn(dim, generator=g)) if with_D else None
-    dout = torch.randn(batch, dim, L, generator=g)
-    return dict(u=u, delta=delta, A=A, B=Bm, C=Cm, D=D, z=z, delta_bias=bias, dout=dout)
 
 
 def scan_case(name, **kw):
@@ -95,13 +79,6 @@ def mamba_block_case():
     for k, p in m.named_parameters():
         rec["grad." + k] = p.grad.numpy()
     np.savez_compressed(os.path.join(OUT, "mamba_block_cfg1.npz"), **rec)
-
-
-def unit_ball_centers(B, G, seed):
-    g = torch.Generator().manual_seed(seed)
-    p = torch.randn(B, G, 3, generator=g)
-    p = p - p.mean(1, keepdim=True)
-    return p / p.norm(dim=-1).max(dim=1)[0][:, None, None]
 
 
 SPECTRAL_COMBOS = [

@@ -7,7 +7,7 @@ from si_mamba_amd import _lib
 if os.environ.get("SIMAMBA_LIB"):
     _lib.LIB_PATH = os.environ["SIMAMBA_LIB"]
 from si_mamba_amd import selective_scan_fn
-from oracle.gen_golden import scan_inputs
+from si_mamba_amd.synthetic import scan_inputs
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--shapes", default="256x768x128,64x768x1024")

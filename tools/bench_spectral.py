@@ -1,7 +1,7 @@
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from si_mamba_amd import spectral
-from oracle.gen_golden import unit_ball_centers
+from si_mamba_amd.synthetic import unit_ball_centers
 dev = torch.device("cuda:0")
 for B, G in [(64, 128), (128, 128), (256, 128), (64, 64), (512, 64)]:
     c = unit_ball_centers(B, G, 0).to(dev)

@@ -4,7 +4,7 @@ import json, os, sys, time, platform
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from oracle import scan_ref, spectral_ref
-from oracle.gen_golden import scan_inputs, unit_ball_centers
+from si_mamba_amd.synthetic import scan_inputs, unit_ball_centers
 
 
 def med(fn, n=5, warm=1):

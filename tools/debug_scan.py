@@ -1,7 +1,7 @@
 import torch, sys
 sys.path.insert(0, '.')
 from oracle import scan_ref
-from oracle.gen_golden import scan_inputs
+from si_mamba_amd.synthetic import scan_inputs
 from si_mamba_amd import selective_scan_fn
 dev = torch.device('cuda:0')
 def run(b, d, L, N, seed=0):
