@@ -57,7 +57,7 @@ extern "C" {
 #define SIMAMBA_E_DSTATE     -4   /* dstate must be in [1,16] */
 #define SIMAMBA_E_WIDTH      -5   /* conv width must be in [2,4] */
 #define SIMAMBA_E_WORKSPACE  -6
-#define SIMAMBA_E_GROUPS     -7   /* G must be in [2,128], knn < G, k <= G */
+#define SIMAMBA_E_GROUPS     -7   /* G in [2,128], knn + 1 <= min(G,32), k (+1) <= G, F in [1,64] */
 #define SIMAMBA_E_ALIGN      -8
 
 /* timesteps per scan chunk; simamba_scan_num_chunks(L) = ceil(L / chunk) */

@@ -14,7 +14,7 @@ extern "C" const char* simamba_strerror(int rc) {
     case SIMAMBA_E_DSTATE: return "simamba: dstate must be in [1,16]";
     case SIMAMBA_E_WIDTH: return "simamba: conv width must be in [2,4]";
     case SIMAMBA_E_WORKSPACE: return "simamba: workspace missing or too small";
-    case SIMAMBA_E_GROUPS: return "simamba: need 2 <= G <= 128, knn + 1 <= G, k (+1) <= G, F >= 1";
+    case SIMAMBA_E_GROUPS: return "simamba: need 2 <= G <= 128, knn + 1 <= min(G, 32), k (+1) <= G, 1 <= F <= 64";
     case SIMAMBA_E_ALIGN: return "simamba: pointer not aligned";
     default: break;
   }

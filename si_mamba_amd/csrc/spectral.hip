@@ -9,12 +9,11 @@
 // round-robin (tournament) ordering: G/2 disjoint column pairs per step, one 16-lane DPP row per pair.
 // This file is compiled WITHOUT fast-math and with -ffp-contract=off so that distances and the
 // Laplacian entries round exactly like the reference's unfused torch ops.
-#include "common.h"
+#include "spectral_common.h"
 
 namespace simamba {
 
-constexpr int kSpecMaxG = 128;
-constexpr int kGraphThreads = 256;
+constexpr int kGraphThreads = 256;   // dist_sum_kernel
 constexpr int kEigThreads = 1024;
 
 // ---------------------------------------------------------------------------------------------
@@ -42,27 +41,28 @@ __global__ void dist_sum_kernel(const float* __restrict__ pts, double* __restric
 }
 
 // ---------------------------------------------------------------------------------------------
-// k-NN adjacency of one sample per workgroup
-__global__ __launch_bounds__(kGraphThreads) void knn_graph_kernel(const float* __restrict__ pts,
-                                                                    float* __restrict__ adj,
-                                                                    const double* __restrict__ dist_sum, int B,
-                                                                    int G, int F, int knn, float alpha,
-                                                                    unsigned flags) {
+// k-NN adjacency of one sample per workgroup.  One lane per graph node: its row of the distance matrix
+// lives in registers (the state loop is unrolled, so every access is statically indexed), the knn+1
+// selection passes are pure VALU compare/select sweeps over those registers (the first version swept an
+// LDS copy of the matrix: 21 x 128 dependent LDS reads per lane, 0.64 ms per batch), the picked
+// (index, weight) lists go to LDS once and feed both index_put phases of the reference.
+constexpr int kKnnMaxK = 32;   // knn + 1 <= 32 list entries per node
+
+__global__ __launch_bounds__(kSpecMaxG) void knn_graph_kernel(const float* __restrict__ pts,
+                                                               float* __restrict__ adj,
+                                                               const double* __restrict__ dist_sum, int B,
+                                                               int G, int F, int knn, float alpha,
+                                                               unsigned flags) {
   extern __shared__ float sm[];
-  float* sDist = sm;            // [G][G+1]
-  float* sAdj = sm + G * (G + 1);   // [G][G+1]
+  float* sAdj = sm;                                   // [G][G+1]
+  float* sP = sAdj + G * (G + 1);                     // [G][F]
+  float* sWt = sP + G * F;                            // [G][kKnnMaxK]
+  int* sNb = reinterpret_cast<int*>(sWt + G * kKnnMaxK);   // [G][kKnnMaxK]
   const int LD = G + 1;
+  const int tid = threadIdx.x;
   const float* P = pts + static_cast<size_t>(blockIdx.x) * G * F;
-  for (int e = threadIdx.x; e < G * G; e += kGraphThreads) {
-    const int i = e / G, j = e - i * G;
-    float d2 = 0.f;
-    for (int f = 0; f < F; ++f) {
-      const float df = P[i * F + f] - P[j * F + f];
-      d2 = d2 + df * df;
-    }
-    sDist[i * LD + j] = sqrtf(d2);
-    sAdj[i * LD + j] = 0.f;
-  }
+  for (int e = tid; e < G * F; e += kSpecMaxG) sP[e] = P[e];
+  for (int e = tid; e < G * LD; e += kSpecMaxG) sAdj[e] = 0.f;
   __syncthreads();
   const bool self_loop = flags & SIMAMBA_SPEC_SELF_LOOP;
   const bool binary = flags & SIMAMBA_SPEC_BINARY;
@@ -72,35 +72,58 @@ __global__ __launch_bounds__(kGraphThreads) void knn_graph_kernel(const float* _
     const float sigma = static_cast<float>(*dist_sum / (static_cast<double>(B) * G * G));
     inv2s2 = 2.f * (sigma * sigma);
   }
+  int nlist = 0;
+  if (tid < G) {
+    const int i = tid;
+    float d[kSpecMaxG];
+#pragma unroll
+    for (int j = 0; j < kSpecMaxG; ++j) {
+      float d2 = 0.f;
+      if (j < G) {
+        for (int f = 0; f < F; ++f) {
+          const float df = sP[i * F + f] - sP[j * F + f];
+          d2 = d2 + df * df;
+        }
+        d[j] = sqrtf(d2);
+      } else {
+        d[j] = __builtin_inff();
+      }
+    }
+    float pv = -1.f;   // previous pick, ascending lexicographic (value, index) order
+    int pi = -1;
+    for (int m = 0; m <= knn; ++m) {
+      float bv = 3.0e38f;
+      int bi = -1;
+#pragma unroll
+      for (int j = 0; j < kSpecMaxG; ++j) {
+        const float v = d[j];
+        const bool after_prev = (v > pv) || (v == pv && j > pi);
+        if (after_prev && (v < bv)) { bv = v; bi = j; }
+      }
+      pv = bv; pi = bi;
+      if (bi < 0) break;                       // NaN distances: nothing left to pick
+      if (m == 0 && !self_loop) continue;      // drop the nearest (the point itself)
+      float w = 1.f;
+      if (!binary) {
+        const float dd = bv * bv;
+        w = (flags & SIMAMBA_SPEC_SIGMA_MEAN) ? expf(-dd / inv2s2) : expf(-1.f * alpha * dd);
+      }
+      sNb[i * kKnnMaxK + nlist] = bi;
+      sWt[i * kKnnMaxK + nlist] = w;
+      ++nlist;
+    }
+  }
   // two phases like the reference's two index_put calls: A[i, nn] = w, then A[nn, i] = w
   for (int phase = 0; phase < (symmetric ? 2 : 1); ++phase) {
-    if (threadIdx.x < G) {
-      const int i = threadIdx.x;
-      float pv = -1.f;   // previous (value, index) in ascending lexicographic order
-      int pi = -1;
-      for (int m = 0; m <= knn; ++m) {
-        float bv = 3.0e38f;
-        int bi = -1;
-        for (int j = 0; j < G; ++j) {
-          const float v = sDist[i * LD + j];
-          const bool after_prev = (v > pv) || (v == pv && j > pi);
-          if (after_prev && (v < bv)) { bv = v; bi = j; }
-        }
-        pv = bv; pi = bi;
-        if (bi < 0) break;                       // NaN distances: nothing left to pick
-        if (m == 0 && !self_loop) continue;      // drop the nearest (the point itself)
-        float w = 1.f;
-        if (!binary) {
-          const float dd = bv * bv;
-          w = (flags & SIMAMBA_SPEC_SIGMA_MEAN) ? expf(-dd / inv2s2) : expf(-1.f * alpha * dd);
-        }
-        if (phase == 0) sAdj[i * LD + bi] = w; else sAdj[bi * LD + i] = w;
-      }
+    for (int q = 0; q < nlist; ++q) {
+      const int bi = sNb[tid * kKnnMaxK + q];
+      const float w = sWt[tid * kKnnMaxK + q];
+      if (phase == 0) sAdj[tid * LD + bi] = w; else sAdj[bi * LD + tid] = w;
     }
     __syncthreads();
   }
   float* out = adj + static_cast<size_t>(blockIdx.x) * G * G;
-  for (int e = threadIdx.x; e < G * G; e += kGraphThreads) {
+  for (int e = tid; e < G * G; e += kSpecMaxG) {
     const int i = e / G, j = e - i * G;
     out[e] = sAdj[i * LD + j];
   }
@@ -119,16 +142,6 @@ __global__ __launch_bounds__(kGraphThreads) void knn_graph_kernel(const float* _
 // two columns (16-byte LDS accesses), so a step of G/2 disjoint pairs needs ONE workgroup barrier (the
 // two-sided form needs three plus a serial parameter phase and measured 6.2 ms per batch of 64).
 // Columns are stored as contiguous rows Wt[p][:].
-struct EigArgs {
-  const float* adj;
-  float* evals;
-  float* evecs;
-  long long* order;
-  float* all_evals;
-  float* all_evecs;
-  int B, G, k;
-  unsigned flags;
-};
 
 constexpr int kEigLD = kSpecMaxG + 4;     // row stride of the LDS image (floats), keeps rows 16-B aligned
 constexpr int kEigVec = kSpecMaxG / 64;   // 16-byte chunks of a column per lane (lane l: floats 4l.., 64+4l..)
@@ -356,7 +369,7 @@ extern "C" size_t simamba_spectral_workspace_bytes(int B, int G) {
 // the value never changes afterwards, so this is not observable state)
 static void ensure_lds_attrs() {
   static const bool once = [] {
-    const int cap = 2 * kSpecMaxG * (kSpecMaxG + 1) * 4;   // knn_graph_kernel's two G x (G+1) tiles
+    const int cap = 4 * (kSpecMaxG * (kSpecMaxG + 1) + kSpecMaxG * 64 + 2 * kSpecMaxG * kKnnMaxK);   // knn_graph_kernel
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(laplacian_eig_kernel),
                         hipFuncAttributeMaxDynamicSharedMemorySize, cap);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(knn_graph_kernel),
@@ -377,7 +390,7 @@ extern "C" int simamba_knn_graph(const float* points, float* adj, void* workspac
   if (!points || !adj) return SIMAMBA_E_NULLPTR;
   int rc = check_groups(B, G);
   if (rc) return rc;
-  if (F < 1 || knn < 0 || knn + 1 > G) return SIMAMBA_E_GROUPS;
+  if (F < 1 || F > 64 || knn < 0 || knn + 1 > G || knn + 1 > kKnnMaxK) return SIMAMBA_E_GROUPS;
   if (B == 0) return SIMAMBA_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
   double* acc = nullptr;
@@ -389,8 +402,8 @@ extern "C" int simamba_knn_graph(const float* points, float* adj, void* workspac
     hipLaunchKernelGGL(dist_sum_kernel, dim3(B), dim3(kGraphThreads), 0, s, points, acc, G, F);
   }
   ensure_lds_attrs();
-  const size_t smem = sizeof(float) * 2 * G * (G + 1);
-  hipLaunchKernelGGL(knn_graph_kernel, dim3(B), dim3(kGraphThreads), smem, s, points, adj, acc, B, G, F, knn, alpha,
+  const size_t smem = sizeof(float) * (static_cast<size_t>(G) * (G + 1) + G * F + 2 * G * kKnnMaxK);
+  hipLaunchKernelGGL(knn_graph_kernel, dim3(B), dim3(kSpecMaxG), smem, s, points, adj, acc, B, G, F, knn, alpha,
                      flags);
   return static_cast<int>(hipGetLastError());
 }
@@ -405,6 +418,10 @@ extern "C" int simamba_laplacian_topk(const float* adj, float* evals, float* eve
   if (k < 0 || need > G) return SIMAMBA_E_GROUPS;
   if (B == 0) return SIMAMBA_OK;
   EigArgs a{adj, evals, evecs, order, all_evals, all_evecs, B, G, k, flags};
+  // top-k only: Householder tridiagonalisation + bisection + inverse iteration (spectral_tridiag.hip);
+  // the full spectrum / full basis (never used by the reference's forward) stays on the Jacobi kernel
+  if (!all_evals && !all_evecs && need <= kTdMaxSel && G >= 3)
+    return launch_tridiag_topk(a, static_cast<hipStream_t>(stream));
   const size_t smem = sizeof(float) * kSpecMaxG * kEigLD;
   ensure_lds_attrs();
   hipLaunchKernelGGL(laplacian_eig_kernel, dim3(B), dim3(kEigThreads), smem, static_cast<hipStream_t>(stream), a);
