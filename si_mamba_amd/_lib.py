@@ -154,14 +154,9 @@ def kernel_times():
 
 
 def scan_workspace(batch, dim, seqlen, dstate, device):
-    """Scratch that opts a forward call into the one-lane-per-channel kernel (scan_fwd_seq.hip).
-
-    Off unless SIMAMBA_SEQ_FWD=1: on MI355X that kernel issues half the VALU instructions of the row-scan
-    kernel but measures the same 163 us at (256,768,128,16), so the simpler
-    kernel stays the default; the switch keeps the alternative testable.
-    """
+    """Scratch the forward entry point asks for (simamba_scan_fwd_workspace_bytes): none since ABI 3's
+    lane-per-channel kernel reads B / C in place, so this returns None; kept so callers stay written
+    against the ABI's workspace contract."""
     import torch
-    if os.environ.get("SIMAMBA_SEQ_FWD", "0") != "1":
-        return None
     n = load().simamba_scan_fwd_workspace_bytes(batch, dim, seqlen, dstate)
     return torch.empty(n, device=device, dtype=torch.uint8) if n else None

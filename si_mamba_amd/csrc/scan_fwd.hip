@@ -3,6 +3,7 @@
 // Replaces selective_scan_cuda.fwd of mamba-ssm as reached from the reference's
 // models/block.py:72.  Algorithmic HBM bytes: 4*B*D*L*s (u, delta, z, out) + 2*B*N*L*s (B, C)
 // + small; the (B_t, C_t) tile is re-read from L2 once per 16*R channels.
+#include <cstdlib>
 #include "scan_common.h"
 
 namespace simamba {
@@ -158,22 +159,25 @@ static int launch_fwd(const ScanArgs& a, hipStream_t s) {
 
 int scan_fwd_seq_dispatch(const void* u, const void* delta, const float* A, const void* B, const void* C, const float* D,
                           const void* z, const float* delta_bias, void* out, float* x_ckpt, float* last_state,
-                          int batch, int dim, int seqlen, int dstate, int io_dtype, int delta_softplus,
-                          long long z_bs, long long bc_bs, long long bc_ns, long long bc_ts, int vec, int nchunks128,
-                          void* workspace, hipStream_t s);
+                          int batch, int dim, int seqlen, int io_dtype, int delta_softplus, long long z_bs,
+                          long long bc_bs, long long bc_ns, long long bc_ts, int nchunks128, hipStream_t s);
 
-// rows (batch * dim) from which one row per lane still gives every SIMD >= 1.5 waves
+// The lane-per-channel kernel (scan_fwd_seq.hip) is taken from this many (batch, channel) rows on.
 constexpr long long kSeqMinRows = 98304;
+
+static bool seq_path_wanted(long long rows) {
+  long long min_rows = kSeqMinRows;
+  if (const char* e = getenv("SIMAMBA_SEQ_MIN_ROWS")) min_rows = atoll(e);   // tuning knobs (tools/bench_scan.py)
+  if (const char* e = getenv("SIMAMBA_SEQ_FWD")) return atoi(e) != 0 && rows >= min_rows;
+  return rows >= min_rows;
+}
 
 }  // namespace simamba
 
 using namespace simamba;
 
-extern "C" size_t simamba_scan_fwd_workspace_bytes(int batch, int dim, int seqlen, int dstate) {
-  if (batch <= 0 || dim <= 0 || seqlen <= 0 || dstate != kMaxState) return 0;
-  if (static_cast<long long>(batch) * dim < kSeqMinRows) return 0;
-  if (static_cast<long long>(batch) * dim * seqlen >= (1ll << 30)) return 0;   // kernel uses 32-bit element offsets
-  return sizeof(float) * 32 * static_cast<size_t>(batch) * seqlen;
+extern "C" size_t simamba_scan_fwd_workspace_bytes(int, int, int, int) {
+  return 0;   // no forward variant needs scratch memory any more (ABI kept: callers may pass NULL / 0)
 }
 
 extern "C" int simamba_scan_num_chunks(int seqlen) {
@@ -210,12 +214,13 @@ extern "C" int simamba_selective_scan_fwd(const void* u, const void* delta, cons
   a.vec = ((seqlen * esz) % 16 == 0) && aligned16(u) && aligned16(delta) && aligned16(out) &&
           (!z || (aligned16(z) && (a.z_bs * esz) % 16 == 0));
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const size_t need = simamba_scan_fwd_workspace_bytes(batch, dim, seqlen, dstate);
-  if (need && a.vec && workspace && ws_bytes >= need && aligned16(workspace) &&
-      static_cast<long long>(batch) * a.z_bs < (1ll << 31))
+  (void)workspace; (void)ws_bytes;
+  const long long rows = static_cast<long long>(batch) * dim;
+  if (dstate == kMaxState && a.vec && seq_path_wanted(rows) && rows * seqlen < (1ll << 30) &&
+      static_cast<long long>(batch) * a.z_bs < (1ll << 30) && (reinterpret_cast<uintptr_t>(A) & 15u) == 0 &&
+      a.bc_ns >= 0 && a.bc_ts >= 0 && (kMaxState - 1) * a.bc_ns + (seqlen - 1) * a.bc_ts < (1ll << 30))
     return scan_fwd_seq_dispatch(u, delta, A, B, C, D, z, delta_bias, out, x_ckpt, last_state, batch, dim, seqlen,
-                                 dstate, io_dtype, delta_softplus, a.z_bs, a.bc_bs, a.bc_ns, a.bc_ts, a.vec,
-                                 a.nchunks, workspace, s);
+                                 io_dtype, delta_softplus, a.z_bs, a.bc_bs, a.bc_ns, a.bc_ts, a.nchunks, s);
   // channels per workgroup: amortise the (B_t,C_t) staging, but keep >= ~3 workgroups per CU
   int passes = 4;
   while (passes > 1 && static_cast<long long>(batch) * ((dim + 16 * passes - 1) / (16 * passes)) < 768) passes >>= 1;

@@ -37,9 +37,8 @@ def test_version_strerror_and_chunks():
     assert lib.simamba_scan_num_chunks(129) == 2
     assert lib.simamba_scan_num_chunks(1024) == 8
     assert lib.simamba_spectral_workspace_bytes(4, 128) == 256 + 4 * 128 * 128 * 4
-    assert lib.simamba_scan_fwd_workspace_bytes(64, 768, 1024, 16) == 0          # too few rows: row-scan kernel
-    assert lib.simamba_scan_fwd_workspace_bytes(256, 768, 128, 16) == 256 * 128 * 32 * 4
-    assert lib.simamba_scan_fwd_workspace_bytes(256, 768, 128, 8) == 0
+    assert lib.simamba_scan_fwd_workspace_bytes(64, 768, 1024, 16) == 0          # no forward kernel needs scratch
+    assert lib.simamba_scan_fwd_workspace_bytes(256, 768, 128, 16) == 0
 
 
 def test_argument_validation_precedes_any_launch():

@@ -184,15 +184,18 @@ def test_scan_backward_full_size_against_row_subset(device):
 
 
 # ---- the one-lane-per-channel forward (taken when batch*dim >= 98304 and rows are pack-aligned) ----------
-@pytest.mark.parametrize("L,dtype", [(16, torch.float32), (40, torch.float32), (132, torch.float32),
-                                     (260, torch.float32), (136, torch.bfloat16)])
-def test_scan_seq_kernel_path(L, dtype, device, monkeypatch):
+@pytest.mark.parametrize("L,dtype,split", [(16, torch.float32, 2), (40, torch.float32, 1), (132, torch.float32, 2),
+                                           (260, torch.float32, 4), (260, torch.float32, 1),
+                                           (128, torch.float32, 0), (136, torch.bfloat16, 2),
+                                           (264, torch.bfloat16, 4)])
+def test_scan_seq_kernel_path(L, dtype, split, device, monkeypatch):
     """Same parity bar as the row-scan kernel, on a row subset (the full tensor is too slow for the CPU
     oracle), including the chunk checkpoints it hands to the backward (L > 128) and the final state."""
     from si_mamba_amd import _lib, selective_scan_fn
     monkeypatch.setenv("SIMAMBA_SEQ_FWD", "1")
-    B, D, N = 128, 768, 16
-    assert _lib.load().simamba_scan_fwd_workspace_bytes(B, D, L, N) > 0     # this shape takes the seq kernel
+    if split:      # a channel's 16 states are split over `split` adjacent lanes; 0 = the dispatcher's own choice
+        monkeypatch.setenv("SIMAMBA_SEQ_LPC", str(split))
+    B, D, N = 128, 768, 16          # batch * dim = 98304 rows: the dispatcher's threshold for this kernel
     inp = scan_inputs(B, D, L, N, seed=L)
     t = {k: v.to(device) for k, v in inp.items()}
     for k in ("u", "delta", "z", "B", "C", "dout"):
