@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define SIMAMBA_ABI_VERSION 3
+#define SIMAMBA_ABI_VERSION 4
 
 #define SIMAMBA_F32  0
 #define SIMAMBA_BF16 1
@@ -152,6 +152,35 @@ int simamba_add_layer_norm_bwd(const void* dnormed, const float* dresidual_out,
                                const float* weight, const float* rowscale, float* dresidual,
                                void* dhidden, float* dwb_partial, int batch, int rows_per_batch,
                                int dim, int hidden_dtype, int out_dtype, void* stream);
+
+/*
+ * Patch-encoder streaming ops (reference models/point_mamba.py:46-73, Encoder: Conv1d - BatchNorm1d - ReLU -
+ * Conv1d, max over the n points of a patch; the 1x1 convolutions are GEMMs on token-major (rows, C) tensors).
+ *
+ * simamba_bn_relu_fwd: y = relu(BatchNorm(x + g)) with g[r / group][c] an optional per-group additive term
+ * (gterm == NULL: none).  training != 0: batch statistics over all rows (biased variance for the
+ * normalisation, unbiased for running_var; running_* updated with `momentum` when non-NULL), written to
+ * mean / invstd (C) for the backward; training == 0: running statistics.  weight / bias may be NULL (1 / 0).
+ *   x, y : (rows, C) io_dtype ; gterm : (rows / group, C) fp32 ; partial : (simamba_bn_relu_grid(rows), 2, C)
+ *   fp32 scratch.  C % 4 == 0, C <= 1024 ; with gterm: 256 % group == 0 and rows % group == 0.
+ * simamba_bn_relu_bwd: dx (rows, C) io_dtype, dgterm (rows / group, C) fp32 or NULL (= sum of dx over each
+ *   group), dweight, dbias (C) fp32 ; same partial scratch.
+ * simamba_group_max_fwd/bwd: out[g][c] = max_r x[g][r][c] over r < n (first maximum; NaN propagates), idx the
+ *   arg max as uint8 (n <= 256); backward routes dout to that row and writes zeros elsewhere (one pass).
+ */
+int simamba_bn_relu_grid(long long rows);
+int simamba_bn_relu_fwd(const void* x, const float* gterm, int group, const float* weight, const float* bias,
+                        float* running_mean, float* running_var, float momentum, float eps, int training,
+                        void* y, float* mean, float* invstd, float* partial, long long rows, int C,
+                        int io_dtype, void* stream);
+int simamba_bn_relu_bwd(const void* dy, const void* x, const float* gterm, int group, const float* weight,
+                        const float* bias, const float* mean, const float* invstd, void* dx, float* dgterm,
+                        float* dweight, float* dbias, float* partial, long long rows, int C, int io_dtype,
+                        int training, void* stream);
+int simamba_group_max_fwd(const void* x, void* out, unsigned char* idx, long long groups, int n, int C,
+                          int io_dtype, void* stream);
+int simamba_group_max_bwd(const void* dout, const unsigned char* idx, void* dx, long long groups, int n, int C,
+                          int io_dtype, void* stream);
 
 /* ---- spectral ordering ---------------------------------------------------------------- */
 #define SIMAMBA_SPEC_SYMMETRIC   0x01u  /* also write A[j,i] for every kNN edge (i,j)          */

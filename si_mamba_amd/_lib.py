@@ -25,7 +25,7 @@ SPEC_SIGMA_MEAN = 0x20
 # name -> (restype, argtypes); mirrors include/simamba.h one to one
 _P = c_void_p
 _LL = c_longlong
-ABI_VERSION = 3
+ABI_VERSION = 4
 SIGNATURES = {
     "simamba_abi_version": (c_int, []),
     "simamba_strerror": (c_char_p, [c_int]),
@@ -46,6 +46,13 @@ SIGNATURES = {
                                            c_int, c_int, _P]),
     "simamba_add_layer_norm_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int,
                                            c_int, c_int, _P]),
+    "simamba_bn_relu_grid": (c_int, [_LL]),
+    "simamba_bn_relu_fwd": (c_int, [_P, _P, c_int, _P, _P, _P, _P, c_float, c_float, c_int, _P, _P, _P, _P, _LL, c_int,
+                                    c_int, _P]),
+    "simamba_bn_relu_bwd": (c_int, [_P, _P, _P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _LL, c_int, c_int, c_int,
+                                    _P]),
+    "simamba_group_max_fwd": (c_int, [_P, _P, _P, _LL, c_int, c_int, c_int, _P]),
+    "simamba_group_max_bwd": (c_int, [_P, _P, _P, _LL, c_int, c_int, c_int, _P]),
     "simamba_knn_graph": (c_int, [_P, _P, _P, c_size_t, c_int, c_int, c_int, c_int, c_float, c_uint, _P]),
     "simamba_laplacian_topk": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_uint, _P]),
     "simamba_spectral_workspace_bytes": (c_size_t, [c_int, c_int]),

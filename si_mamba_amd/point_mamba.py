@@ -8,8 +8,9 @@ reference state_dict loads unchanged.  What runs on the HIP kernels: the spectra
 
 ``Group`` (farthest-point sampling + k-NN grouping) and ``Encoder`` (mini-PointNet) sit BEFORE the
 hot path ("next" row 1).  The reference gets FPS / k-NN from pytorch3d CUDA ops
-(:93, :96), which are absent here: FPS is the HIP kernel of csrc/fps.hip, the k-NN grouping and the
-encoder are plain torch (cdist/topk, GEMMs).
+(:93, :96), which are absent here: FPS is the HIP kernel of csrc/fps.hip, the k-NN grouping is plain torch
+(cdist/topk), the encoder is library GEMMs around the HIP BatchNorm+ReLU / per-patch max kernels
+(csrc/bn_relu.hip).
 """
 from __future__ import annotations
 
@@ -20,6 +21,7 @@ import torch.nn as nn
 
 from . import grouping, spectral
 from .block import MixerModel
+from .encoder_ops import bn_relu_fn, group_max_fn
 
 
 class Group(nn.Module):
@@ -57,6 +59,7 @@ class Encoder(nn.Module):
     def __init__(self, encoder_channel):
         super().__init__()
         self.encoder_channel = encoder_channel
+        self.fused = True          # HIP BatchNorm+ReLU / max kernels on the GPU (False: composed torch ops)
         self.first_conv = nn.Sequential(nn.Conv1d(3, 128, 1), nn.BatchNorm1d(128), nn.ReLU(inplace=True),
                                         nn.Conv1d(128, 256, 1))
         self.second_conv = nn.Sequential(nn.Conv1d(512, 512, 1), nn.BatchNorm1d(512), nn.ReLU(inplace=True),
@@ -65,17 +68,31 @@ class Encoder(nn.Module):
     def forward(self, point_groups):
         """(B, G, n, 3) -> (B, G, C).  The four 1x1 convolutions are plain GEMMs on the (B*G*n, C)
         token-major view (same Conv1d / BatchNorm1d parameters, same arithmetic); this avoids the
-        NCHW<->NHWC transposes MIOpen inserts around its implicit-GEMM kernels."""
+        NCHW<->NHWC transposes MIOpen inserts around its implicit-GEMM kernels.  On the GPU the
+        BatchNorm+ReLU pairs and the per-patch max run on the HIP streaming kernels (encoder_ops.py) and
+        the concat of the global feature (:64-66) becomes a per-patch additive term of the second BN:
+        cat([g, f]) @ W^T == f @ W[:, C:]^T + g @ W[:, :C]^T."""
         bs, g, n, _ = point_groups.shape
         c1, bn1, _, c2 = self.first_conv
         c3, bn2, _, c4 = self.second_conv
+        lin = torch.nn.functional.linear
         x = point_groups.reshape(bs * g * n, 3)
-        x = torch.relu(bn1(torch.nn.functional.linear(x, c1.weight.squeeze(-1), c1.bias)))
-        f = torch.nn.functional.linear(x, c2.weight.squeeze(-1), c2.bias).view(bs * g, n, 256)
+        if self.fused and x.is_cuda and 256 % n == 0:
+            x = bn_relu_fn(lin(x, c1.weight.squeeze(-1), c1.bias), bn1)
+            f = lin(x, c2.weight.squeeze(-1), c2.bias)                                  # (B*G*n, 256)
+            cf = f.shape[1]
+            fg = group_max_fn(f.view(bs * g, n, cf))                                     # (B*G, 256)
+            w3 = c3.weight.squeeze(-1)
+            gterm = lin(fg, w3[:, :cf], c3.bias)                                         # (B*G, 512): global half + bias
+            x = bn_relu_fn(lin(f, w3[:, cf:]), bn2, gterm=gterm, group=n)
+            f = lin(x, c4.weight.squeeze(-1), c4.bias)
+            return group_max_fn(f.view(bs * g, n, self.encoder_channel)).reshape(bs, g, self.encoder_channel)
+        x = torch.relu(bn1(lin(x, c1.weight.squeeze(-1), c1.bias)))
+        f = lin(x, c2.weight.squeeze(-1), c2.bias).view(bs * g, n, 256)
         fg = f.max(dim=1, keepdim=True)[0]
         x = torch.cat([fg.expand(-1, n, -1), f], dim=2).reshape(bs * g * n, 512)
-        x = torch.relu(bn2(torch.nn.functional.linear(x, c3.weight.squeeze(-1), c3.bias)))
-        f = torch.nn.functional.linear(x, c4.weight.squeeze(-1), c4.bias).view(bs * g, n, self.encoder_channel)
+        x = torch.relu(bn2(lin(x, c3.weight.squeeze(-1), c3.bias)))
+        f = lin(x, c4.weight.squeeze(-1), c4.bias).view(bs * g, n, self.encoder_channel)
         return f.max(dim=1)[0].reshape(bs, g, self.encoder_channel)
 
 
