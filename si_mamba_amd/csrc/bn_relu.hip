@@ -87,6 +87,7 @@ __global__ __launch_bounds__(kBnMaxThreads) void bn_stats_kernel(BnArgs p) {
   float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
   const long long r0 = static_cast<long long>(blockIdx.x) * kBnChunk;
   const long long r1 = min(r0 + kBnChunk, p.rows);
+#pragma unroll 4
   for (long long r = r0 + rlane; r < r1; r += rl) {
     float v[4];
     load_c4<T>(x + r * C + 4 * cl, v);
@@ -104,18 +105,37 @@ __global__ __launch_bounds__(kBnMaxThreads) void bn_stats_kernel(BnArgs p) {
   reduce_row_lanes(s1, s2, sm, tpr, rl, cl, rlane, p.partial + static_cast<size_t>(blockIdx.x) * 2 * C, C);
 }
 
-// finalize: one thread per channel, fp64 combination of the per-workgroup partials
-template <typename T>
-__global__ void bn_stats_finalize_kernel(const void* x, const float* gterm, const float* partial, int grid,
-                                         long long rows, int C, float eps, float momentum, float* mean,
-                                         float* invstd, float* running_mean, float* running_var) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double S1 = 0.0, S2 = 0.0;
-  for (int g = 0; g < grid; ++g) {
-    S1 += partial[(static_cast<size_t>(g) * 2 + 0) * C + c];
-    S2 += partial[(static_cast<size_t>(g) * 2 + 1) * C + c];
+// finalize: fp64 combination of the per-workgroup partials.  A workgroup of 256 threads owns kFinCh channels:
+// thread (pl, c) sums partials pl, pl + kFinPl, ... of channel c, the kFinPl lanes are combined through LDS.
+constexpr int kFinCh = 16, kFinPl = 16;
+
+__device__ __forceinline__ void finalize_sums(const float* __restrict__ partial, int grid, int C, int c, int pl,
+                                              bool valid, double (*sm)[kFinPl][kFinCh], double& S1, double& S2) {
+  double a1 = 0.0, a2 = 0.0;
+  if (valid) {
+#pragma unroll 4
+    for (int g = pl; g < grid; g += kFinPl) {
+      a1 += partial[(static_cast<size_t>(g) * 2 + 0) * C + c];
+      a2 += partial[(static_cast<size_t>(g) * 2 + 1) * C + c];
+    }
   }
+  const int cl = threadIdx.x % kFinCh;
+  sm[0][pl][cl] = a1;
+  sm[1][pl][cl] = a2;
+  __syncthreads();
+  S1 = 0.0; S2 = 0.0;
+  for (int k = 0; k < kFinPl; ++k) { S1 += sm[0][k][cl]; S2 += sm[1][k][cl]; }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kFinCh * kFinPl) void bn_stats_finalize_kernel(
+    const void* x, const float* gterm, const float* partial, int grid, long long rows, int C, float eps,
+    float momentum, float* mean, float* invstd, float* running_mean, float* running_var) {
+  __shared__ double sm[2][kFinPl][kFinCh];
+  const int c = blockIdx.x * kFinCh + threadIdx.x % kFinCh, pl = threadIdx.x / kFinCh;
+  double S1, S2;
+  finalize_sums(partial, grid, C, c, pl, c < C, sm, S1, S2);
+  if (c >= C || pl != 0) return;
   float K = to_f32<T>(static_cast<const T*>(x)[c]);
   if (gterm) K += gterm[c];
   const double n = static_cast<double>(rows);
@@ -157,6 +177,7 @@ __global__ __launch_bounds__(kBnMaxThreads) void bn_relu_apply_kernel(BnArgs p) 
   }
   const long long r0 = static_cast<long long>(blockIdx.x) * kBnChunk;
   const long long r1 = min(r0 + kBnChunk, p.rows);
+#pragma unroll 4
   for (long long r = r0 + rlane; r < r1; r += rl) {
     float v[4];
     load_c4<T>(x + r * C + 4 * cl, v);
@@ -190,6 +211,7 @@ __global__ __launch_bounds__(kBnMaxThreads) void bn_relu_bwd_reduce_kernel(BnArg
   float sb[4] = {0.f, 0.f, 0.f, 0.f}, sw[4] = {0.f, 0.f, 0.f, 0.f};
   const long long r0 = static_cast<long long>(blockIdx.x) * kBnChunk;
   const long long r1 = min(r0 + kBnChunk, p.rows);
+#pragma unroll 4
   for (long long r = r0 + rlane; r < r1; r += rl) {
     float v[4], d[4];
     load_c4<T>(x + r * C + 4 * cl, v);
@@ -208,14 +230,13 @@ __global__ __launch_bounds__(kBnMaxThreads) void bn_relu_bwd_reduce_kernel(BnArg
   reduce_row_lanes(sb, sw, sm, tpr, rl, cl, rlane, p.partial + static_cast<size_t>(blockIdx.x) * 2 * C, C);
 }
 
-__global__ void bn_bwd_finalize_kernel(const float* partial, int grid, int C, float* dweight, float* dbias) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double Sb = 0.0, Sw = 0.0;
-  for (int g = 0; g < grid; ++g) {
-    Sb += partial[(static_cast<size_t>(g) * 2 + 0) * C + c];
-    Sw += partial[(static_cast<size_t>(g) * 2 + 1) * C + c];
-  }
+__global__ __launch_bounds__(kFinCh * kFinPl) void bn_bwd_finalize_kernel(const float* partial, int grid, int C,
+                                                                             float* dweight, float* dbias) {
+  __shared__ double sm[2][kFinPl][kFinCh];
+  const int c = blockIdx.x * kFinCh + threadIdx.x % kFinCh, pl = threadIdx.x / kFinCh;
+  double Sb, Sw;
+  finalize_sums(partial, grid, C, c, pl, c < C, sm, Sb, Sw);
+  if (c >= C || pl != 0) return;
   dbias[c] = static_cast<float>(Sb);
   dweight[c] = static_cast<float>(Sw);
 }
@@ -247,6 +268,7 @@ __global__ __launch_bounds__(kBnMaxThreads) void bn_relu_bwd_dx_kernel(BnArgs p,
   for (long long gbase = r0; gbase < r1; gbase += group) {
     float gs[4] = {0.f, 0.f, 0.f, 0.f};
     const long long gend = min(gbase + group, r1);
+#pragma unroll 4
     for (long long r = gbase + rlane; r < gend; r += rl) {
       float v[4], d[4], o[4];
       load_c4<T>(x + r * C + 4 * cl, v);
@@ -364,11 +386,11 @@ extern "C" int simamba_bn_relu_fwd(const void* x, const float* gterm, int group,
   if (training) {
     if (f32) {
       hipLaunchKernelGGL(bn_stats_kernel<float>, dim3(grid), block, smem, s, a);
-      hipLaunchKernelGGL(bn_stats_finalize_kernel<float>, dim3((C + 127) / 128), dim3(128), 0, s, x, gterm, partial,
+      hipLaunchKernelGGL(bn_stats_finalize_kernel<float>, dim3((C + kFinCh - 1) / kFinCh), dim3(kFinCh * kFinPl), 0, s, x, gterm, partial,
                          grid, rows, C, eps, momentum, mean, invstd, running_mean, running_var);
     } else {
       hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, dim3(grid), block, smem, s, a);
-      hipLaunchKernelGGL(bn_stats_finalize_kernel<bf16_t>, dim3((C + 127) / 128), dim3(128), 0, s, x, gterm, partial,
+      hipLaunchKernelGGL(bn_stats_finalize_kernel<bf16_t>, dim3((C + kFinCh - 1) / kFinCh), dim3(kFinCh * kFinPl), 0, s, x, gterm, partial,
                          grid, rows, C, eps, momentum, mean, invstd, running_mean, running_var);
     }
   } else {
@@ -400,7 +422,8 @@ extern "C" int simamba_bn_relu_bwd(const void* dy, const void* x, const float* g
   const bool f32 = io_dtype == SIMAMBA_F32;
   if (f32) hipLaunchKernelGGL(bn_relu_bwd_reduce_kernel<float>, dim3(grid), block, sizeof(float) * 2 * C * rl, s, a);
   else hipLaunchKernelGGL(bn_relu_bwd_reduce_kernel<bf16_t>, dim3(grid), block, sizeof(float) * 2 * C * rl, s, a);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, s, partial, grid, C, dweight, dbias);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kFinCh * kFinPl), 0, s, partial, grid, C,
+                     dweight, dbias);
   if (f32) hipLaunchKernelGGL(bn_relu_bwd_dx_kernel<float>, dim3(grid), block, sizeof(float) * C * rl, s, a, dweight, dbias);
   else hipLaunchKernelGGL(bn_relu_bwd_dx_kernel<bf16_t>, dim3(grid), block, sizeof(float) * C * rl, s, a, dweight, dbias);
   return static_cast<int>(hipGetLastError());
