@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define SIMAMBA_ABI_VERSION 4
+#define SIMAMBA_ABI_VERSION 5
 
 #define SIMAMBA_F32  0
 #define SIMAMBA_BF16 1
@@ -161,10 +161,13 @@ int simamba_add_layer_norm_bwd(const void* dnormed, const float* dresidual_out,
  * (gterm == NULL: none).  training != 0: batch statistics over all rows (biased variance for the
  * normalisation, unbiased for running_var; running_* updated with `momentum` when non-NULL), written to
  * mean / invstd (C) for the backward; training == 0: running statistics.  weight / bias may be NULL (1 / 0).
- *   x, y : (rows, C) io_dtype ; gterm : (rows / group, C) fp32 ; partial : (simamba_bn_relu_grid(rows), 2, C)
- *   fp32 scratch.  C % 4 == 0, C <= 1024 ; with gterm: 256 % group == 0 and rows % group == 0.
- * simamba_bn_relu_bwd: dx (rows, C) io_dtype, dgterm (rows / group, C) fp32 or NULL (= sum of dx over each
- *   group), dweight, dbias (C) fp32 ; same partial scratch.
+ *   x, y : (rows, C) io_dtype with row stride ld elements (0 = C; a channel slice of a wider tensor is
+ *   processed in place: C <= 1024 per call, wider layers are done slice by slice) ; gterm : (rows / group, C)
+ *   fp32 ; partial : (simamba_bn_relu_grid(rows), 2, C) fp32 scratch.  C % 4 == 0, ld % 4 == 0,
+ *   rows % group == 0.
+ * simamba_bn_relu_bwd: dx (rows, C) io_dtype (same ld), dgterm (rows / dgroup, C) fp32 or NULL (= sum of dx over
+ *   runs of dgroup rows; 256 % dgroup == 0 -- for group > 256 the caller sums group / 256 consecutive rows of
+ *   it), dweight, dbias (C) fp32 ; same partial scratch.
  * simamba_group_max_fwd/bwd: out[g][c] = max_r x[g][r][c] over r < n (first maximum; NaN propagates), idx the
  *   arg max as uint8 (n <= 256); backward routes dout to that row and writes zeros elsewhere (one pass).
  */
@@ -172,11 +175,11 @@ int simamba_bn_relu_grid(long long rows);
 int simamba_bn_relu_fwd(const void* x, const float* gterm, int group, const float* weight, const float* bias,
                         float* running_mean, float* running_var, float momentum, float eps, int training,
                         void* y, float* mean, float* invstd, float* partial, long long rows, int C,
-                        int io_dtype, void* stream);
+                        long long ld, int io_dtype, void* stream);
 int simamba_bn_relu_bwd(const void* dy, const void* x, const float* gterm, int group, const float* weight,
                         const float* bias, const float* mean, const float* invstd, void* dx, float* dgterm,
-                        float* dweight, float* dbias, float* partial, long long rows, int C, int io_dtype,
-                        int training, void* stream);
+                        int dgroup, float* dweight, float* dbias, float* partial, long long rows, int C,
+                        long long ld, int io_dtype, int training, void* stream);
 int simamba_group_max_fwd(const void* x, void* out, unsigned char* idx, long long groups, int n, int C,
                           int io_dtype, void* stream);
 int simamba_group_max_bwd(const void* dout, const unsigned char* idx, void* dx, long long groups, int n, int C,

@@ -25,7 +25,7 @@ SPEC_SIGMA_MEAN = 0x20
 # name -> (restype, argtypes); mirrors include/simamba.h one to one
 _P = c_void_p
 _LL = c_longlong
-ABI_VERSION = 4
+ABI_VERSION = 5
 SIGNATURES = {
     "simamba_abi_version": (c_int, []),
     "simamba_strerror": (c_char_p, [c_int]),
@@ -48,9 +48,9 @@ SIGNATURES = {
                                            c_int, c_int, _P]),
     "simamba_bn_relu_grid": (c_int, [_LL]),
     "simamba_bn_relu_fwd": (c_int, [_P, _P, c_int, _P, _P, _P, _P, c_float, c_float, c_int, _P, _P, _P, _P, _LL, c_int,
-                                    c_int, _P]),
-    "simamba_bn_relu_bwd": (c_int, [_P, _P, _P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _LL, c_int, c_int, c_int,
-                                    _P]),
+                                    _LL, c_int, _P]),
+    "simamba_bn_relu_bwd": (c_int, [_P, _P, _P, c_int, _P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _LL, c_int, _LL,
+                                    c_int, c_int, _P]),
     "simamba_group_max_fwd": (c_int, [_P, _P, _P, _LL, c_int, c_int, c_int, _P]),
     "simamba_group_max_bwd": (c_int, [_P, _P, _P, _LL, c_int, c_int, c_int, _P]),
     "simamba_knn_graph": (c_int, [_P, _P, _P, c_size_t, c_int, c_int, c_int, c_int, c_float, c_uint, _P]),

@@ -37,7 +37,8 @@ struct BnArgs {
   float* dgterm;
   float* partial;     // (grid, 2, C)
   long long rows;
-  int C, group, training;
+  long long ld;       // row stride (elements) of x / y / dy / dx: channel slices of a wider tensor are processed in place
+  int C, group, dgroup, training;
 };
 
 template <typename T>
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(kBnMaxThreads) void bn_stats_kernel(BnArgs p) {
 #pragma unroll 4
   for (long long r = r0 + rlane; r < r1; r += rl) {
     float v[4];
-    load_c4<T>(x + r * C + 4 * cl, v);
+    load_c4<T>(x + r * p.ld + 4 * cl, v);
     if (p.gterm) {
       const float4 g = *reinterpret_cast<const float4*>(p.gterm + (r / p.group) * C + 4 * cl);
       v[0] += g.x; v[1] += g.y; v[2] += g.z; v[3] += g.w;
@@ -180,7 +181,7 @@ __global__ __launch_bounds__(kBnMaxThreads) void bn_relu_apply_kernel(BnArgs p) 
 #pragma unroll 4
   for (long long r = r0 + rlane; r < r1; r += rl) {
     float v[4];
-    load_c4<T>(x + r * C + 4 * cl, v);
+    load_c4<T>(x + r * p.ld + 4 * cl, v);
     if (p.gterm) {
       const float4 g = *reinterpret_cast<const float4*>(p.gterm + (r / p.group) * C + 4 * cl);
       v[0] += g.x; v[1] += g.y; v[2] += g.z; v[3] += g.w;
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(kBnMaxThreads) void bn_relu_apply_kernel(BnArgs p) 
     float o[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) o[i] = fmaxf(fmaf(v[i], scale[i], shift[i]), 0.f);
-    store_c4<T>(y + r * C + 4 * cl, o);
+    store_c4<T>(y + r * p.ld + 4 * cl, o);
   }
 }
 
@@ -214,8 +215,8 @@ __global__ __launch_bounds__(kBnMaxThreads) void bn_relu_bwd_reduce_kernel(BnArg
 #pragma unroll 4
   for (long long r = r0 + rlane; r < r1; r += rl) {
     float v[4], d[4];
-    load_c4<T>(x + r * C + 4 * cl, v);
-    load_c4<T>(dy + r * C + 4 * cl, d);
+    load_c4<T>(x + r * p.ld + 4 * cl, v);
+    load_c4<T>(dy + r * p.ld + 4 * cl, d);
     if (p.gterm) {
       const float4 g = *reinterpret_cast<const float4*>(p.gterm + (r / p.group) * C + 4 * cl);
       v[0] += g.x; v[1] += g.y; v[2] += g.z; v[3] += g.w;
@@ -264,15 +265,15 @@ __global__ __launch_bounds__(kBnMaxThreads) void bn_relu_bwd_dx_kernel(BnArgs p,
   }
   const long long r0 = static_cast<long long>(blockIdx.x) * kBnChunk;
   const long long r1 = min(r0 + kBnChunk, p.rows);
-  const int group = p.dgterm ? p.group : kBnChunk;
+  const int group = p.dgterm ? p.dgroup : kBnChunk;
   for (long long gbase = r0; gbase < r1; gbase += group) {
     float gs[4] = {0.f, 0.f, 0.f, 0.f};
     const long long gend = min(gbase + group, r1);
 #pragma unroll 4
     for (long long r = gbase + rlane; r < gend; r += rl) {
       float v[4], d[4], o[4];
-      load_c4<T>(x + r * C + 4 * cl, v);
-      load_c4<T>(dy + r * C + 4 * cl, d);
+      load_c4<T>(x + r * p.ld + 4 * cl, v);
+      load_c4<T>(dy + r * p.ld + 4 * cl, d);
       if (p.gterm) {
         const float4 g = *reinterpret_cast<const float4*>(p.gterm + (r / p.group) * C + 4 * cl);
         v[0] += g.x; v[1] += g.y; v[2] += g.z; v[3] += g.w;
@@ -284,7 +285,7 @@ __global__ __launch_bounds__(kBnMaxThreads) void bn_relu_bwd_dx_kernel(BnArgs p,
         o[i] = scale[i] * (dr - kb[i] - xh * kw[i]);
         gs[i] += o[i];
       }
-      store_c4<T>(dx + r * C + 4 * cl, o);
+      store_c4<T>(dx + r * p.ld + 4 * cl, o);
     }
     if (p.dgterm) {
       __syncthreads();                              // previous group's reads of sm are done
@@ -294,7 +295,7 @@ __global__ __launch_bounds__(kBnMaxThreads) void bn_relu_bwd_dx_kernel(BnArgs p,
       for (int e = threadIdx.x; e < C; e += blockDim.x) {
         float acc = 0.f;
         for (int r = 0; r < rl; ++r) acc += sm[r * C + e];
-        p.dgterm[(gbase / p.group) * C + e] = acc;
+        p.dgterm[(gbase / p.dgroup) * C + e] = acc;
       }
     }
   }
@@ -345,9 +346,9 @@ __global__ void group_max_bwd_kernel(const T* __restrict__ dout, const unsigned 
   store_c4<T>(dx + gr * C + c, o);
 }
 
-static bool bn_shape_ok(long long rows, int C, int group, bool has_g) {
-  if (rows <= 0 || C < 4 || C > 4 * kBnMaxThreads || (C % 4) != 0) return false;
-  if (has_g && (group <= 0 || (kBnChunk % group) != 0 || (rows % group) != 0)) return false;
+static bool bn_shape_ok(long long rows, int C, long long ld, int group, bool has_g) {
+  if (rows <= 0 || C < 4 || C > 4 * kBnMaxThreads || (C % 4) != 0 || ld < C || (ld % 4) != 0) return false;
+  if (has_g && (group <= 0 || (rows % group) != 0)) return false;
   return true;
 }
 static dim3 bn_block(int C) {
@@ -368,17 +369,19 @@ extern "C" int simamba_bn_relu_grid(long long rows) {
 extern "C" int simamba_bn_relu_fwd(const void* x, const float* gterm, int group, const float* weight,
                                    const float* bias, float* running_mean, float* running_var, float momentum,
                                    float eps, int training, void* y, float* mean, float* invstd, float* partial,
-                                   long long rows, int C, int io_dtype, void* stream) {
+                                   long long rows, int C, long long ld, int io_dtype, void* stream) {
   if (io_dtype != SIMAMBA_F32 && io_dtype != SIMAMBA_BF16) return SIMAMBA_E_DTYPE;
   if (rows == 0) return SIMAMBA_OK;
-  if (!bn_shape_ok(rows, C, group, gterm != nullptr)) return SIMAMBA_E_SHAPE;
+  if (ld == 0) ld = C;
+  if (!bn_shape_ok(rows, C, ld, group, gterm != nullptr)) return SIMAMBA_E_SHAPE;
   if (!x || !y || !mean || !invstd) return SIMAMBA_E_NULLPTR;
   if (training && !partial) return SIMAMBA_E_NULLPTR;
   if (!training && (!running_mean || !running_var)) return SIMAMBA_E_NULLPTR;
   hipStream_t s = static_cast<hipStream_t>(stream);
   BnArgs a{};
   a.x = x; a.gterm = gterm; a.weight = weight; a.bias = bias; a.mean = mean; a.invstd = invstd;
-  a.y = y; a.partial = partial; a.rows = rows; a.C = C; a.group = group; a.training = training;
+  a.y = y; a.partial = partial; a.rows = rows; a.ld = ld; a.C = C; a.group = group; a.dgroup = group;
+  a.training = training;
   const int grid = simamba_bn_relu_grid(rows);
   const dim3 block = bn_block(C);
   const size_t smem = sizeof(float) * 2 * C * bn_row_lanes(C);
@@ -404,18 +407,20 @@ extern "C" int simamba_bn_relu_fwd(const void* x, const float* gterm, int group,
 
 extern "C" int simamba_bn_relu_bwd(const void* dy, const void* x, const float* gterm, int group,
                                    const float* weight, const float* bias, const float* mean, const float* invstd,
-                                   void* dx, float* dgterm, float* dweight, float* dbias, float* partial,
-                                   long long rows, int C, int io_dtype, int training, void* stream) {
+                                   void* dx, float* dgterm, int dgroup, float* dweight, float* dbias, float* partial,
+                                   long long rows, int C, long long ld, int io_dtype, int training, void* stream) {
   if (io_dtype != SIMAMBA_F32 && io_dtype != SIMAMBA_BF16) return SIMAMBA_E_DTYPE;
   if (rows == 0) return SIMAMBA_OK;
-  if (!bn_shape_ok(rows, C, group, gterm != nullptr)) return SIMAMBA_E_SHAPE;
+  if (ld == 0) ld = C;
+  if (!bn_shape_ok(rows, C, ld, group, gterm != nullptr)) return SIMAMBA_E_SHAPE;
+  if (dgterm && (dgroup <= 0 || (kBnChunk % dgroup) != 0 || (rows % dgroup) != 0)) return SIMAMBA_E_SHAPE;
   if (!dy || !x || !mean || !invstd || !dx || !dweight || !dbias || !partial) return SIMAMBA_E_NULLPTR;
   if (dgterm && !gterm) return SIMAMBA_E_NULLPTR;
   hipStream_t s = static_cast<hipStream_t>(stream);
   BnArgs a{};
   a.x = x; a.gterm = gterm; a.weight = weight; a.bias = bias; a.mean = mean; a.invstd = invstd;
-  a.dy = dy; a.y = dx; a.dgterm = dgterm; a.partial = partial; a.rows = rows; a.C = C; a.group = group;
-  a.training = training;
+  a.dy = dy; a.y = dx; a.dgterm = dgterm; a.partial = partial; a.rows = rows; a.ld = ld; a.C = C; a.group = group;
+  a.dgroup = dgroup; a.training = training;
   const int grid = simamba_bn_relu_grid(rows);
   const dim3 block = bn_block(C);
   const int rl = bn_row_lanes(C);

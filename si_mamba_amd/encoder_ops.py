@@ -15,6 +15,19 @@ import torch
 from . import _lib
 
 
+_BN_MAX_C = 1024     # channels per kernel call; wider layers go slice by slice (in place, row stride = C)
+_BN_CHUNK = 256      # rows per workgroup in csrc/bn_relu.hip: the granularity of its per-group dx sums
+
+
+def _slices(C):
+    return [(c0, min(c0 + _BN_MAX_C, C)) for c0 in range(0, C, _BN_MAX_C)]
+
+
+def _off(t, elems):
+    """data_ptr of a contiguous tensor advanced by `elems` elements (None stays None)."""
+    return None if t is None else t.data_ptr() + elems * t.element_size()
+
+
 class BnReluFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gterm, group, weight, bias, running_mean, running_var, momentum, eps, training):
@@ -30,13 +43,19 @@ class BnReluFn(torch.autograd.Function):
         y = torch.empty_like(xc)
         mean = torch.empty(C, device=dev, dtype=torch.float32)
         invstd = torch.empty(C, device=dev, dtype=torch.float32)
-        part = torch.empty(lib.simamba_bn_relu_grid(rows), 2, C, device=dev, dtype=torch.float32)
+        grid = lib.simamba_bn_relu_grid(rows)
+        part = torch.empty(grid, 2, min(C, _BN_MAX_C), device=dev, dtype=torch.float32)
+        gs = []
         with torch.cuda.device(dev), _lib.timed("bn_relu_fwd", dev):
-            rc = lib.simamba_bn_relu_fwd(xc.data_ptr(), _lib.ptr(g), int(group), _lib.ptr(w), _lib.ptr(b),
-                                         _lib.ptr(running_mean), _lib.ptr(running_var), float(momentum), float(eps),
-                                         int(bool(training)), y.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
-                                         part.data_ptr(), rows, C, code, _lib.stream_ptr(dev))
-        _lib.check(rc, "simamba_bn_relu_fwd")
+            for c0, c1 in _slices(C):
+                gsl = None if g is None else (g if (c0 == 0 and c1 == C) else g[:, c0:c1].contiguous())
+                gs.append(gsl)
+                rc = lib.simamba_bn_relu_fwd(_off(xc, c0), _lib.ptr(gsl), int(group), _off(w, c0), _off(b, c0),
+                                             _off(running_mean, c0), _off(running_var, c0), float(momentum),
+                                             float(eps), int(bool(training)), _off(y, c0), _off(mean, c0),
+                                             _off(invstd, c0), part.data_ptr(), rows, c1 - c0, C, code,
+                                             _lib.stream_ptr(dev))
+                _lib.check(rc, "simamba_bn_relu_fwd")
         ctx.save_for_backward(xc, g, w, b, mean, invstd)
         ctx.meta = (int(group), bool(training), code, x.dtype,
                     None if gterm is None else gterm.dtype,
@@ -53,16 +72,30 @@ class BnReluFn(torch.autograd.Function):
         dev = xc.device
         dyc = dy.to(xc.dtype).contiguous()
         dx = torch.empty_like(xc)
-        dg = None if g is None else torch.empty_like(g)
         dw = torch.empty(C, device=dev, dtype=torch.float32)
         db = torch.empty(C, device=dev, dtype=torch.float32)
+        # the kernel sums dx over runs of dgroup <= 256 rows; wider groups are finished here
+        dgroup = 0 if g is None else (group if _BN_CHUNK % group == 0 else _BN_CHUNK)
+        if g is not None and dgroup == _BN_CHUNK and group % _BN_CHUNK != 0:
+            raise ValueError("bn_relu_fn: group must divide 256 or be a multiple of it")
+        dgs = []
         with torch.cuda.device(dev), _lib.timed("bn_relu_bwd", dev):
-            rc = lib.simamba_bn_relu_bwd(dyc.data_ptr(), xc.data_ptr(), _lib.ptr(g), group, _lib.ptr(w), _lib.ptr(b),
-                                         mean.data_ptr(), invstd.data_ptr(), dx.data_ptr(), _lib.ptr(dg),
-                                         dw.data_ptr(), db.data_ptr(), ctx.part.data_ptr(), rows, C, code,
-                                         int(training), _lib.stream_ptr(dev))
-        _lib.check(rc, "simamba_bn_relu_bwd")
-        return (dx.to(xdtype), None if dg is None else dg.to(gdtype), None,
+            for c0, c1 in _slices(C):
+                gsl = None if g is None else (g if (c0 == 0 and c1 == C) else g[:, c0:c1].contiguous())
+                dg = None if g is None else torch.empty(rows // dgroup, c1 - c0, device=dev, dtype=torch.float32)
+                dgs.append(dg)
+                rc = lib.simamba_bn_relu_bwd(_off(dyc, c0), _off(xc, c0), _lib.ptr(gsl), group, _off(w, c0),
+                                             _off(b, c0), _off(mean, c0), _off(invstd, c0), _off(dx, c0), _lib.ptr(dg),
+                                             dgroup, _off(dw, c0), _off(db, c0), ctx.part.data_ptr(), rows, c1 - c0, C,
+                                             code, int(training), _lib.stream_ptr(dev))
+                _lib.check(rc, "simamba_bn_relu_bwd")
+        dgt = None
+        if g is not None:
+            dgt = dgs[0] if len(dgs) == 1 else torch.cat(dgs, dim=1)
+            if dgroup != group:
+                dgt = dgt.view(rows // group, group // dgroup, C).sum(1)
+            dgt = dgt.to(gdtype)
+        return (dx.to(xdtype), dgt, None,
                 None if wdtype is None else dw.to(wdtype), None if bdtype is None else db.to(bdtype),
                 None, None, None, None, None)
 

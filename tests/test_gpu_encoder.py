@@ -15,6 +15,7 @@ def nerr(a, b):
 
 @pytest.mark.parametrize("rows,C,group,dtype", [(4096, 128, 0, torch.float32), (2048, 512, 32, torch.float32),
                                                (1000, 96, 0, torch.float32), (768, 384, 16, torch.float32),
+                                               (1024, 1536, 0, torch.float32), (2048, 1280, 512, torch.float32),
                                                (4096, 256, 32, torch.bfloat16)])
 def test_bn_relu_matches_torch(rows, C, group, dtype, device):
     from si_mamba_amd.encoder_ops import bn_relu_fn
@@ -118,9 +119,14 @@ def test_bn_relu_argument_errors(device):
     m = torch.zeros(8, device=device)
     part = torch.zeros(1, 2, 8, device=device)
     # group must divide 256 and rows
+    # group must divide rows
     rc = lib.simamba_bn_relu_fwd(x.data_ptr(), m.data_ptr(), 7, None, None, None, None, 0.1, 1e-5, 1, x.data_ptr(),
-                                 m.data_ptr(), m.data_ptr(), part.data_ptr(), 64, 8, 0, None)
-    assert rc == -1 or rc < 0
+                                 m.data_ptr(), m.data_ptr(), part.data_ptr(), 64, 8, 0, 0, None)
+    assert rc < 0
+    # C % 4, and row stride >= C
     rc = lib.simamba_bn_relu_fwd(x.data_ptr(), None, 0, None, None, None, None, 0.1, 1e-5, 1, x.data_ptr(),
-                                 m.data_ptr(), m.data_ptr(), part.data_ptr(), 64, 6, 0, None)
+                                 m.data_ptr(), m.data_ptr(), part.data_ptr(), 64, 6, 0, 0, None)
+    assert rc < 0
+    rc = lib.simamba_bn_relu_fwd(x.data_ptr(), None, 0, None, None, None, None, 0.1, 1e-5, 1, x.data_ptr(),
+                                 m.data_ptr(), m.data_ptr(), part.data_ptr(), 64, 8, 4, 0, None)
     assert rc < 0
