@@ -185,6 +185,22 @@ int simamba_group_max_fwd(const void* x, void* out, unsigned char* idx, long lon
 int simamba_group_max_bwd(const void* dout, const unsigned char* idx, void* dx, long long groups, int n, int C,
                           int io_dtype, void* stream);
 
+/*
+ * Feature propagation of the part-segmentation head (reference part_segmentation/models/pointnet2_utils.py:262-305,
+ * PointNetFeaturePropagation.forward): for every query point the three nearest of the sample's S centres
+ * (squared distance in the reference's expanded form, ties to the lower index), weights 1/(d + 1e-8) normalised
+ * to sum 1, and the weighted sum of the three centres' feature rows.
+ *   xyz1 : (batch, N, 3) fp32 query points ; xyz2 : (batch, S, 3) fp32 centres ; idx : (batch, N, 3) int32 ;
+ *   weight : (batch, N, 3) fp32 ; feats : (batch, S, C) io_dtype ; out : (batch, N, C) io_dtype ;
+ *   dfeats : (batch, S, C) fp32, zeroed by the call, accumulated with float atomics.  C % 4 == 0, S <= 8192.
+ */
+int simamba_three_nn(const float* xyz1, const float* xyz2, int* idx, float* weight, int batch, int N, int S,
+                     void* stream);
+int simamba_three_interpolate_fwd(const void* feats, const int* idx, const float* weight, void* out, int batch,
+                                  int N, int S, int C, int io_dtype, void* stream);
+int simamba_three_interpolate_bwd(const void* dout, const int* idx, const float* weight, float* dfeats, int batch,
+                                  int N, int S, int C, int io_dtype, void* stream);
+
 /* ---- spectral ordering ---------------------------------------------------------------- */
 #define SIMAMBA_SPEC_SYMMETRIC   0x01u  /* also write A[j,i] for every kNN edge (i,j)          */
 #define SIMAMBA_SPEC_SELF_LOOP   0x02u  /* keep the nearest neighbour (the point itself)        */

@@ -1,0 +1,98 @@
+"""GPU parity of the part-segmentation path (BASELINE config 5): the 3-NN interpolation
+kernels against the oracle's restatement of pointnet2_utils.py:262-305, and the whole PartSegMamba forward against
+the oracle composition (CPU mixers + reference-layout head) on the same weights.  Tolerance 1e-3 (fp32)."""
+import pytest
+import torch
+
+from oracle import scan_ref, seg_ref
+
+pytestmark = pytest.mark.gpu
+
+
+def nerr(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+def _clouds(B, N, seed):
+    g = torch.Generator().manual_seed(seed)
+    p = torch.randn(B, N, 3, generator=g)
+    p = p - p.mean(1, keepdim=True)
+    return p / p.norm(dim=-1).max(dim=1)[0][:, None, None]
+
+
+@pytest.mark.parametrize("B,N,S,C,dtype", [(2, 512, 64, 64, torch.float32), (3, 300, 37, 1152, torch.float32),
+                                           (1, 2048, 256, 128, torch.float32), (2, 256, 3, 8, torch.float32),
+                                           (2, 512, 64, 64, torch.bfloat16)])
+def test_three_nn_interpolate_matches_oracle(B, N, S, C, dtype, device):
+    from si_mamba_amd.interp import three_interpolate, three_nn
+    pts = _clouds(B, N, N + S)
+    g = torch.Generator().manual_seed(C)
+    centres = pts[:, torch.randperm(N, generator=g)[:S]].clone()       # centres coincide with points (as after FPS)
+    if S >= 8:
+        centres[:, S // 2:S // 2 + 2] = centres[:, :2]                  # exact duplicates: ties go to the lower index
+    feats = torch.randn(B, S, C, generator=g)
+    dout = torch.randn(B, N, C, generator=g)
+    want, widx, ww = seg_ref.three_nn_interpolate(pts, centres, feats.to(dtype).float())
+    idx, w = three_nn(pts.to(device), centres.to(device))
+    if S >= 3:
+        # the neighbour SETS agree wherever the third and fourth distances are separated; weights within 1e-4
+        d = seg_ref.square_distance(pts, centres).sort(dim=-1, stable=True)[0]
+        clear = ((d[:, :, 3] - d[:, :, 2]) > 1e-5) if S > 3 else torch.ones(B, N, dtype=torch.bool)
+        same = (idx.cpu().long().sort(-1)[0] == widx.sort(-1)[0]).all(-1)
+        assert bool(same[clear].all())
+    f = feats.to(device).to(dtype).requires_grad_(True)
+    out = three_interpolate(f, idx, w)
+    assert nerr(out, want) < (2e-4 if dtype == torch.float32 else 2e-2)
+    out.backward(dout.to(device).to(dtype))
+    fr = feats.to(dtype).float().clone().requires_grad_(True)
+    (seg_ref.index_points(fr, idx.cpu().long()) * w.cpu().view(B, N, 3, 1)).sum(2).backward(dout.to(dtype).float())
+    assert nerr(f.grad, fr.grad) < (2e-4 if dtype == torch.float32 else 2e-2)
+
+
+@pytest.mark.parametrize("method", ["HLT", "SAST", "Point_MAMBA"])
+def test_partseg_forward_matches_oracle_composition(method, device):
+    from si_mamba_amd.seg import PartSegMamba, default_seg_config
+    torch.manual_seed(0)
+    cfg = default_seg_config(trans_dim=64, depth=4, fetch_idx=(1, 2, 3), num_group=32, group_size=16, drop_path=0.,
+                             drop_path_rate=0., knn_graph=6, method=method, k_top_eigenvectors=3)
+    m = PartSegMamba(50, cfg).to(device).eval()
+    m.hlt_rand = False
+    B, N = 2, 512
+    pts = _clouds(B, N, 3).transpose(1, 2).contiguous()                 # (B, 3, N)
+    label = torch.zeros(B, 16); label[0, 3] = 1; label[1, 7] = 1
+    with torch.no_grad():
+        got = m(pts.to(device), label.to(device)).cpu()
+        # the ordering itself is covered by tests/test_gpu_spectral.py: take the device's tokens in sequence order
+        nb, center, _ = m.group_divider(pts.transpose(1, 2).contiguous().to(device))
+        x, spos, scenter = m.order_tokens(m.encoder(nb), m.pos_embed(center), center)
+        x, spos, scenter = x.cpu(), spos.cpu(), scenter.cpu()
+    cpu = m.cpu()
+    mixers = []
+    for layer in cpu.blocks.layers:
+        r = scan_ref.MambaRef(cfg.trans_dim)
+        r.load_state_dict(layer.mixer.state_dict())
+        mixers.append(r.eval())
+    with torch.no_grad():
+        feats = seg_ref.mixer_taps(cpu.blocks, mixers, x, spos)
+        want = seg_ref.seg_head(cpu, pts, label, scenter, feats)
+    assert got.shape == (B, N, 50)
+    assert (got - want).abs().max() < 2e-3 * max(1.0, float(want.abs().max()))
+
+
+def test_partseg_train_step_reference_sizes(device):
+    """BASELINE config 5 architecture (12 blocks, d=384, 128 patches, HLT -> L=256, 2048 points): fwd+bwd."""
+    from si_mamba_amd.seg import PartSegMamba, get_loss
+    torch.manual_seed(0)
+    m = PartSegMamba(50).to(device).train()
+    B, N = 4, 2048
+    pts = _clouds(B, N, 5).transpose(1, 2).contiguous().to(device)
+    label = torch.nn.functional.one_hot(torch.tensor([0, 3, 7, 15]), 16).float().to(device)
+    target = torch.randint(0, 50, (B, N), device=device)
+    out = m(pts, label)
+    assert out.shape == (B, N, 50)
+    loss = get_loss()(out.reshape(-1, 50), target.view(-1))
+    loss.backward()
+    assert torch.isfinite(loss)
+    missing = [k for k, p in m.named_parameters() if p.grad is None or not torch.isfinite(p.grad).all()]
+    assert not missing, missing

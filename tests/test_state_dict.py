@@ -58,3 +58,18 @@ def test_import_shim_resolves_reference_imports():
     except ImportError:
         raised = True
     assert raised   # reference models/block.py:9-12 then falls back to nn.LayerNorm
+
+
+def test_partseg_state_dict_names():
+    """Parameter names / shapes of the reference's get_model (pt_mamba.py:420-480) at the reference sizes."""
+    from si_mamba_amd.seg import PartSegMamba
+    sd = PartSegMamba(50).state_dict()
+    want = {"propagation_0.mlp_convs.0.weight": (1536, 1155, 1), "propagation_0.mlp_convs.1.weight": (1024, 1536, 1),
+            "propagation_0.mlp_bns.1.running_var": (1024,), "convs1.weight": (512, 3392, 1),
+            "convs2.weight": (256, 512, 1), "convs3.weight": (50, 256, 1), "bns1.weight": (512,),
+            "label_conv.0.weight": (64, 16, 1), "label_conv.1.running_mean": (64,), "norm.weight": (384,),
+            "blocks.norm_f.weight": (384,), "blocks.layers.11.mixer.A_log": (768, 16),
+            "blocks.layers.0.mixer.in_proj.weight": (1536, 384), "encoder.second_conv.3.weight": (384, 512, 1),
+            "pos_embed.2.weight": (384, 128)}
+    for k, shp in want.items():
+        assert k in sd and tuple(sd[k].shape) == shp, k
