@@ -201,6 +201,19 @@ int simamba_three_interpolate_fwd(const void* feats, const int* idx, const float
 int simamba_three_interpolate_bwd(const void* dout, const int* idx, const float* weight, float* dfeats, int batch,
                                   int N, int S, int C, int io_dtype, void* stream);
 
+/*
+ * Chamfer distance of the MAE pre-training loss (reference models/point_mamba.py:2950, :3203:
+ * pytorch3d.loss.chamfer_distance(pred, gt, batch_reduction=None) -- squared L2 to the nearest neighbour, mean over
+ * each set's points, both directions summed; one value per pair of sets).
+ *   pred : (pairs, n, 3) fp32 ; gt : (pairs, m, 3) fp32 ; dist : (pairs) fp32 ; idx1 : (pairs, n) uint8 nearest gt
+ *   of every prediction ; idx2 : (pairs, m) uint8 nearest prediction of every gt point ; n, m <= 64.
+ * Backward: dpred (pairs, n, 3) fp32 from ddist (pairs) (gt carries no gradient).
+ */
+int simamba_chamfer_fwd(const float* pred, const float* gt, float* dist, unsigned char* idx1, unsigned char* idx2,
+                        long long pairs, int n, int m, void* stream);
+int simamba_chamfer_bwd(const float* pred, const float* gt, const float* ddist, const unsigned char* idx1,
+                        const unsigned char* idx2, float* dpred, long long pairs, int n, int m, void* stream);
+
 /* ---- spectral ordering ---------------------------------------------------------------- */
 #define SIMAMBA_SPEC_SYMMETRIC   0x01u  /* also write A[j,i] for every kNN edge (i,j)          */
 #define SIMAMBA_SPEC_SELF_LOOP   0x02u  /* keep the nearest neighbour (the point itself)        */

@@ -1,0 +1,44 @@
+"""Part-segmentation train step (BASELINE config 5 shapes: 2048 points -> 128 patches, HLT ordering L=256 or SAST
+L=1024), fwd+bwd+AdamW: clouds/s on one GPU (tuning / reporting tool, not the judged bench)."""
+import argparse, os, sys, time, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from si_mamba_amd.seg import PartSegMamba, default_seg_config, get_loss
+from si_mamba_amd.synthetic import make_clouds
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=16)
+ap.add_argument("--npoints", type=int, default=2048)
+ap.add_argument("--method", default="HLT")
+ap.add_argument("--dtype", default="bf16")
+ap.add_argument("--steps", type=int, default=8)
+args = ap.parse_args()
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+m = PartSegMamba(50, default_seg_config(method=args.method)).to(dev).train()
+opt = torch.optim.AdamW(m.parameters(), lr=2e-4, weight_decay=0.05, fused=True)
+pts = make_clouds(args.batch, args.npoints, 0).to(dev).transpose(1, 2).contiguous()
+label = torch.nn.functional.one_hot(torch.randint(0, 16, (args.batch,)), 16).float().to(dev)
+target = torch.randint(0, 50, (args.batch, args.npoints), device=dev)
+crit = get_loss()
+amp = torch.autocast("cuda", dtype=torch.bfloat16, enabled=args.dtype == "bf16")
+
+def step():
+    opt.zero_grad(set_to_none=True)
+    with amp:
+        out = m(pts, label)
+    loss = crit(out.reshape(-1, 50), target.view(-1))
+    loss.backward()
+    opt.step()
+    return loss
+
+for _ in range(3):
+    step()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(args.steps):
+    loss = step()
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / args.steps
+print(json.dumps({"workload": f"part segmentation train step, {args.method}, {args.npoints} pts, B={args.batch}, {args.dtype}",
+                  "ms_per_step": round(dt * 1e3, 2), "clouds_per_s": round(args.batch / dt, 1), "loss": float(loss)}))
