@@ -214,6 +214,15 @@ int simamba_chamfer_fwd(const float* pred, const float* gt, float* dist, unsigne
 int simamba_chamfer_bwd(const float* pred, const float* gt, const float* ddist, const unsigned char* idx1,
                         const unsigned char* idx2, float* dpred, long long pairs, int n, int m, void* stream);
 
+/*
+ * k-NN grouping of the tokeniser (reference models/point_mamba.py:96: pytorch3d.ops.knn_points(center, xyz,
+ * K=group_size, return_sorted=False)): idx[b][g][0..K) = the K points of cloud b nearest to centre g, ascending
+ * squared distance (direct differences), ties to the lower point index.
+ *   points : (batch, N, 3) fp32 ; centers : (batch, G, 3) fp32 ; idx : (batch, G, K) int64.  K <= N <= 8192.
+ */
+int simamba_knn_group(const float* points, const float* centers, long long* idx, int batch, int N, int G, int K,
+                      void* stream);
+
 /* ---- spectral ordering ---------------------------------------------------------------- */
 #define SIMAMBA_SPEC_SYMMETRIC   0x01u  /* also write A[j,i] for every kNN edge (i,j)          */
 #define SIMAMBA_SPEC_SELF_LOOP   0x02u  /* keep the nearest neighbour (the point itself)        */

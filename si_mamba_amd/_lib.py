@@ -58,6 +58,7 @@ SIGNATURES = {
     "simamba_three_interpolate_bwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "simamba_chamfer_fwd": (c_int, [_P, _P, _P, _P, _P, _LL, c_int, c_int, _P]),
     "simamba_chamfer_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _LL, c_int, c_int, _P]),
+    "simamba_knn_group": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "simamba_knn_graph": (c_int, [_P, _P, _P, c_size_t, c_int, c_int, c_int, c_int, c_float, c_uint, _P]),
     "simamba_laplacian_topk": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_uint, _P]),
     "simamba_spectral_workspace_bytes": (c_size_t, [c_int, c_int]),

@@ -24,3 +24,19 @@ def sample_farthest_points(points, K):
                                                _lib.stream_ptr(p.device))
     _lib.check(rc, "simamba_farthest_point_sample")
     return centers.to(points.dtype), idx
+
+
+def knn_group(centers, points, K):
+    """(B,G,3) centres, (B,N,3) points -> (B,G,K) int64: the K nearest points of every centre (the reference's
+    pytorch3d.ops.knn_points(center, xyz, K, return_sorted=False).idx at models/point_mamba.py:96)."""
+    _lib.require_gpu(points, "knn_group")
+    lib = _lib.load()
+    p = points.detach().float().contiguous()
+    c = centers.detach().float().contiguous()
+    B, N, _ = p.shape
+    G = c.shape[1]
+    idx = torch.empty(B, G, int(K), device=p.device, dtype=torch.int64)
+    with torch.cuda.device(p.device), _lib.timed("knn_group", p.device):
+        rc = lib.simamba_knn_group(_lib.ptr(p), _lib.ptr(c), _lib.ptr(idx), B, N, G, int(K), _lib.stream_ptr(p.device))
+    _lib.check(rc, "simamba_knn_group")
+    return idx

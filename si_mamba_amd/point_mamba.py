@@ -8,8 +8,8 @@ reference state_dict loads unchanged.  What runs on the HIP kernels: the spectra
 
 ``Group`` (farthest-point sampling + k-NN grouping) and ``Encoder`` (mini-PointNet) sit BEFORE the
 hot path ("next" row 1).  The reference gets FPS / k-NN from pytorch3d CUDA ops
-(:93, :96), which are absent here: FPS is the HIP kernel of csrc/fps.hip, the k-NN grouping is plain torch
-(cdist/topk), the encoder is library GEMMs around the HIP BatchNorm+ReLU / per-patch max kernels
+(:93, :96), which are absent here: FPS and the k-NN grouping are the HIP kernels of csrc/fps.hip and
+csrc/knn_group.hip, the encoder is library GEMMs around the HIP BatchNorm+ReLU / per-patch max kernels
 (csrc/bn_relu.hip).
 """
 from __future__ import annotations
@@ -27,9 +27,10 @@ from .encoder_ops import bn_relu_fn, group_max_fn
 class Group(nn.Module):
     """(B,N,3) -> neighborhood (B,G,M,3) centred, center (B,G,3), neighborhood_org; reference :76-111.
 
-    Farthest-point sampling runs on the HIP kernel (grouping.sample_farthest_points, the counterpart of
-    the pytorch3d call at :93); the k-NN grouping (:96) is cdist + topk in torch.  ``fps_fn`` can be
-    swapped (bench.py's CPU baseline plugs the oracle in).
+    Farthest-point sampling and the k-NN grouping run on HIP kernels (grouping.sample_farthest_points /
+    grouping.knn_group, the counterparts of the pytorch3d calls at :93 and :96; clouds of up to 8192 points,
+    larger ones and CPU tensors take cdist + topk).  ``fps_fn`` can be swapped (bench.py's CPU baseline plugs
+    the oracle in).
     """
 
     def __init__(self, num_group, group_size):
@@ -41,6 +42,8 @@ class Group(nn.Module):
     @torch.no_grad()
     def _indices(self, xyz):
         center, _ = self.fps_fn(xyz, self.num_group)
+        if xyz.is_cuda and xyz.shape[1] <= 8192:
+            return center, grouping.knn_group(center, xyz, self.group_size)
         d = torch.cdist(center, xyz)
         nn_idx = d.topk(self.group_size, dim=-1, largest=False, sorted=False)[1]
         return center, nn_idx

@@ -129,3 +129,28 @@ def test_training_reduces_loss_on_separable_clouds(device):
         pts, y = batch(64)
         acc = float((m(pts).argmax(-1) == y).float().mean())
     assert last < 0.5 * first and acc > 0.9, (first, last, acc)
+
+
+@pytest.mark.parametrize("B,N,G,K", [(4, 1024, 128, 32), (2, 2048, 128, 32), (3, 100, 17, 9), (1, 5000, 64, 32),
+                                     (2, 64, 8, 64)])
+def test_knn_group_matches_exact_neighbours(B, N, G, K, device):
+    """Neighbour sets of csrc/knn_group.hip against a float64 brute force (the reference's pytorch3d knn_points,
+    return_sorted=False, leaves the order open); output order ascending, ties to the lower index."""
+    from si_mamba_amd.grouping import knn_group
+    pts = _clouds(B, N, N + K)
+    centers = pts[:, :G].clone()
+    idx = knn_group(centers.to(device), pts.to(device), K).cpu()
+    d64 = ((centers.double().unsqueeze(2) - pts.double().unsqueeze(1)) ** 2).sum(-1)          # (B,G,N)
+    d32 = (((centers.unsqueeze(2) - pts.unsqueeze(1)) ** 2)[..., 0] + ((centers.unsqueeze(2) - pts.unsqueeze(1)) ** 2)[..., 1]
+           + ((centers.unsqueeze(2) - pts.unsqueeze(1)) ** 2)[..., 2])
+    picked = torch.gather(d32, 2, idx)
+    assert bool((picked[:, :, 1:] >= picked[:, :, :-1]).all())                      # ascending
+    assert bool((idx.sort(-1)[0][:, :, 1:] != idx.sort(-1)[0][:, :, :-1]).all())    # distinct
+    srt = d64.sort(-1)[0]
+    if K < N:
+        clear = (srt[:, :, K] - srt[:, :, K - 1]) > 1e-9                            # boundary not a near-tie
+        want = d64.topk(K, dim=-1, largest=False)[1].sort(-1)[0]
+        same = (idx.sort(-1)[0] == want).all(-1)
+        assert bool(same[clear].all()) and float(clear.float().mean()) > 0.9
+    else:
+        assert bool((idx.sort(-1)[0] == torch.arange(N)).all())
