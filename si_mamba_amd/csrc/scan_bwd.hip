@@ -77,6 +77,7 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_bwd_kernel(ScanArgs p) {
   float* sAcc = sC + kMaxState * LDP;        // [2][kMaxState][LC]   dB / dC of this chunk (cross-wave sum)
   float* sG = sAcc + 2 * kMaxState * LC;     // [16*passes][kMaxState] adjoint state entering from the right
   float* sDf = sG + kRowsPerPass * p.passes * kMaxState;  // [16*passes] delta of the next chunk's first step
+  float* sCk = sDf + kRowsPerPass * p.passes;             // [16 rows][kMaxState] chunk-start states of this pass
 
   const int b = blockIdx.y;
   const int tile_base = blockIdx.x * (kRowsPerPass * p.passes);
@@ -149,12 +150,20 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_bwd_kernel(ScanArgs p) {
       }
       // delta of the step right after this lane's last one (next lane, or next chunk for lane 15)
       const float dnext = row_next(dl[0], last_chunk ? 0.f : sDf[slot]);
-      const float* __restrict__ ck =
-          (c > 0) ? p.x_ckpt + ((static_cast<size_t>(b) * D + dc) * p.nchunks + (c - 1)) * N : nullptr;
+      // chunk-start state h_{t0-1}[n] from the forward's checkpoints: lane n of the row fetches entry n (one
+      // coalesced 64-byte read per row, issued with the tile loads) and parks it in LDS; the state loop then
+      // reads it back row-broadcast.  (Reading x_ckpt inside the state loop cost one exposed global-load
+      // round trip per state: s_waitcnt vmcnt(0) in the middle of the loop.)
+      {
+        const float* ck = p.x_ckpt + ((static_cast<size_t>(b) * D + dc) * p.nchunks + (c > 0 ? c - 1 : 0)) * N;
+        sCk[rowslot * kMaxState + lane16] = (c > 0 && lane16 < N) ? ck[lane16] : 0.f;
+      }
       float dAlane = 0.f;   // lane n of the row ends up holding dA[d][n] of this chunk
 
 #pragma unroll
       for (int n = 0; n < kMaxState; ++n) {
+        // (the runtime guard doubles as a boundary between the unrolled states: compiled away for dstate == 16,
+        //  hipcc interleaves all 16 states and spills 3 KB per lane)
         if (n < N) {
           const float A2n = A2[n];
           const float* bp = sB + n * LDP;
@@ -178,7 +187,10 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_bwd_kernel(ScanArgs p) {
           float P = fast_exp2(A2n * sumd);
           row_scan_inclusive(P, S);
           float h = row_prev(S, 0.f);
-          if (ck) h = fmaf(row_prev(P, 1.f), ck[n], h);
+          {
+            const float hin = sCk[rowslot * kMaxState + n];     // zero-filled when there is no chunk to the left
+            h = fmaf(row_prev(P, 1.f), hin, h);
+          }
           float red[2 * kItems];   // [0,K): dB terms, [K,2K): dC terms
 #pragma unroll
           for (int i = 0; i < kItems; ++i) {
@@ -199,12 +211,13 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_bwd_kernel(ScanArgs p) {
           float Q = fast_exp2(A2n * (sumd - dl[0] + dnext));
           row_scan_inclusive_rev(Q, G);
           float g = row_next(G, 0.f);
-          if (!last_chunk) {
-            const float gcar = sG[slot * kMaxState + n];
+          {
+            // adjoint state entering from the chunk on the right (0 for the last chunk): one straight-line
+            // sequence for every chunk position, the only predicated op is the LDS store of the carry
+            const float gl = sG[slot * kMaxState + n];
+            const float gcar = last_chunk ? 0.f : gl;
             g = fmaf(row_next(Q, 1.f), gcar, g);
             if (c > 0 && lane16 == 0) sG[slot * kMaxState + n] = fmaf(Q, gcar, G);
-          } else if (c > 0 && lane16 == 0) {
-            sG[slot * kMaxState + n] = G;
           }
           float dAacc = 0.f;
 #pragma unroll
@@ -293,7 +306,7 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_bwd_kernel(ScanArgs p) {
 static size_t bwd_smem_bytes(int kItems, int passes) {
   const int LC = 16 * kItems;
   return sizeof(float) * (2 * kMaxState * (LC + 4) + 2 * kMaxState * LC + kRowsPerPass * passes * kMaxState +
-                          kRowsPerPass * passes);
+                          kRowsPerPass * passes + kRowsPerPass * kMaxState);
 }
 
 template <typename T>
