@@ -143,6 +143,11 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm device: the product path has no CPU fallback")
+    # stdout carries exactly one JSON line: RCCL prints a version banner to fd 1 when a communicator is created,
+    # so everything else this process (and the libraries it loads) writes to stdout goes to stderr instead
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     rank, world = sdist.init_dist("nccl" if args.gpus > 1 else None)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
@@ -231,7 +236,8 @@ def main():
             out["headline_scan"] = headline_scan(device)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.npoints, args.groups)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist.is_available() and dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

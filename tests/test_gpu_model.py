@@ -122,8 +122,8 @@ def test_training_reduces_loss_on_separable_clouds(device):
         loss.backward()
         opt.step()
         if it < 3:
-            first = float(loss) if first is None else max(first, float(loss))
-        last = float(loss)
+            first = loss.item() if first is None else max(first, loss.item())
+        last = loss.item()
     m.eval()
     with torch.no_grad():
         pts, y = batch(64)
