@@ -133,10 +133,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-headline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-tuned-gemm", action="store_true",
+                    help="library-default GEMM solutions instead of si_mamba_amd/tuned/gemm_gfx950.csv")
     args = ap.parse_args()
 
     from si_mamba_amd import _lib
     from si_mamba_amd import dist as sdist
+    from si_mamba_amd.gemm_tuning import enable_tuned_gemms
     from si_mamba_amd.point_mamba import PointMamba, default_config
     from si_mamba_amd.synthetic import make_clouds
     import torch.distributed as dist
@@ -155,6 +158,9 @@ def main():
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
     _lib.load()
+    # fp32 library GEMMs take the solutions recorded for this step's shapes (si_mamba_amd/gemm_tuning.py);
+    # look-up only, nothing is tuned inside the run
+    tuned = (not args.no_tuned_gemm) and args.dtype == "f32" and enable_tuned_gemms()
 
     torch.manual_seed(0)                                    # same init on every rank
     cfg = default_config(num_group=args.groups)             # cfgs/finetune_scan_hardest.yaml model block
@@ -212,7 +218,9 @@ def main():
                                    f"{args.npoints} pts -> {args.groups} patches",
                        "global_batch": args.batch * world, "per_gpu_batch": args.batch,
                        "npoints": args.npoints, "patches": args.groups, "mamba_seq_len": L,
-                       "parallelism": f"dp{world}"},
+                       "parallelism": f"dp{world}",
+                       "library_gemm": "tuned solution table (si_mamba_amd/tuned/gemm_gfx950.csv)" if tuned
+                       else "library defaults"},
         }
         if "scan_fwd" in ktimes:
             n, ms = ktimes["scan_fwd"]

@@ -73,3 +73,20 @@ def test_partseg_state_dict_names():
             "pos_embed.2.weight": (384, 128)}
     for k, shp in want.items():
         assert k in sd and tuple(sd[k].shape) == shp, k
+
+
+def test_tuned_gemm_table_is_well_formed():
+    """si_mamba_amd/tuned/gemm_gfx950.csv: validators first, then fp32 entries only (bf16 candidates fault on this
+    image, tools/tune_gemm.py); without a GPU enable_tuned_gemms() is a no-op."""
+    import os
+    from si_mamba_amd import gemm_tuning
+    assert os.path.exists(gemm_tuning.DEFAULT_FILE)
+    rows = [l.strip().split(",") for l in open(gemm_tuning.DEFAULT_FILE) if l.strip()]
+    vals = [r for r in rows if r[0] == "Validator"]
+    ents = [r for r in rows if r[0] != "Validator"]
+    assert {v[1] for v in vals} >= {"PT_VERSION", "HIPBLASLT_VERSION", "ROCBLAS_VERSION", "GCN_ARCH_NAME"}
+    assert any("gfx950" in v[2] for v in vals)
+    assert len(ents) >= 30 and all(len(r) == 4 and "_float_" in r[0] for r in ents)
+    import torch
+    if not torch.cuda.is_available():
+        assert gemm_tuning.enable_tuned_gemms() is False
