@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void interp_fwd_kernel(const T* __restrict__ f
   const int* id = idx + pt * 3;
   const float* w = wgt + pt * 3;
   const T* base = feats + b * S * C + c;
-  float a[4], v[4], acc[4] = {0.f, 0.f, 0.f, 0.f};
+  float v[4], acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     ld4<T>(base + static_cast<long long>(id[k]) * C, v);
@@ -89,7 +89,6 @@ __global__ __launch_bounds__(256) void interp_fwd_kernel(const T* __restrict__ f
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[i] = fmaf(wk, v[i], acc[i]);
   }
-  (void)a;
   Pack<T, 4> pk;
 #pragma unroll
   for (int i = 0; i < 4; ++i) pk.v[i] = from_f32<T>(acc[i]);
