@@ -3,7 +3,8 @@
     python -m oracle.gen_golden            # from the repo root
 
 What pins what
-  * scan_*.npz / conv_*.npz / mamba_block_cfg1.npz / spectral_*.npz are produced by THIS repo's
+  * scan_*.npz / conv_*.npz / mamba_block_cfg1.npz / spectral_*.npz / interp_seg.npz / chamfer_mae.npz are
+    produced by THIS repo's
     CPU restatement (oracle/) with stock CPU torch; they are regression pins of the oracle and
     the inputs/expected outputs of the GPU parity tests.  The reference cannot be imported here
     (its module-level imports need the absent wheels mamba_ssm, pytorch3d, timm, easydict), so
@@ -23,7 +24,7 @@ import sys
 import numpy as np
 import torch
 
-from oracle import scan_ref, spectral_ref
+from oracle import mae_ref, scan_ref, seg_ref, spectral_ref
 from si_mamba_amd.synthetic import scan_inputs, unit_ball_centers  # noqa: F401  (re-exported for the tests)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -122,6 +123,29 @@ def spectral_case(name, B, G, seed, k=4):
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **rec)
 
 
+def interp_case(name, B, N, S, C, seed):
+    """3-NN inverse-distance interpolation (part_segmentation/models/pointnet2_utils.py:285-297)."""
+    pts = unit_ball_centers(B, N, seed)
+    g = torch.Generator().manual_seed(seed)
+    centres = pts[:, torch.randperm(N, generator=g)[:S]].clone()
+    feats = torch.randn(B, S, C, generator=g)
+    out, idx, w = seg_ref.three_nn_interpolate(pts, centres, feats)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), xyz1=pts.numpy(), xyz2=centres.numpy(), feats=feats.numpy(),
+                        out=out.numpy(), idx=idx.numpy().astype(np.int32), weight=w.numpy())
+
+
+def chamfer_case(name, pairs, n, m, seed):
+    """Chamfer-L2 of the MAE loss (pytorch3d semantics, models/point_mamba.py:3203)."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(pairs, n, 3, generator=g, requires_grad=True)
+    y = torch.randn(pairs, m, 3, generator=g)
+    w = torch.rand(pairs, generator=g)
+    d = mae_ref.chamfer_distance(x, y)
+    (d * w).sum().backward()
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), pred=x.detach().numpy(), gt=y.numpy(), wsum=w.numpy(),
+                        dist=d.detach().numpy(), grad_pred=x.grad.numpy())
+
+
 def param_table():
     if not os.path.exists(REF_LOG):
         print("reference log not present; keeping the committed param table", file=sys.stderr)
@@ -155,6 +179,8 @@ def main():
     mamba_block_case()
     spectral_case("spectral_g64", 4, 64, 0)
     spectral_case("spectral_g128", 2, 128, 1)
+    interp_case("interp_seg", 2, 256, 32, 48, 4)
+    chamfer_case("chamfer_mae", 64, 32, 32, 5)
     param_table()
 
 

@@ -39,6 +39,18 @@ def test_chamfer_matches_oracle(pairs, n, m, device):
     assert nerr(xa.grad, xb.grad) < 1e-5
 
 
+def test_chamfer_golden_fixture(device):
+    import os
+    import numpy as np
+    from si_mamba_amd.mae import chamfer_distance
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "chamfer_mae.npz"))
+    x = torch.from_numpy(z["pred"]).to(device).requires_grad_(True)
+    d = chamfer_distance(x, torch.from_numpy(z["gt"]).to(device))
+    (d * torch.from_numpy(z["wsum"]).to(device)).sum().backward()
+    assert nerr(d, torch.from_numpy(z["dist"])) < 1e-5
+    assert nerr(x.grad, torch.from_numpy(z["grad_pred"])) < 1e-5
+
+
 def _oracle_stack(mixer_model, d):
     """MixerModel.forward (models/point_mamba.py:247-258) with CPU oracle mixers carrying the same weights."""
     refs = []

@@ -50,6 +50,17 @@ def test_three_nn_interpolate_matches_oracle(B, N, S, C, dtype, device):
     assert nerr(f.grad, fr.grad) < (2e-4 if dtype == torch.float32 else 2e-2)
 
 
+def test_interp_golden_fixture(device):
+    import os
+    import numpy as np
+    from si_mamba_amd.interp import three_interpolate, three_nn
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "interp_seg.npz"))
+    idx, w = three_nn(torch.from_numpy(z["xyz1"]).to(device), torch.from_numpy(z["xyz2"]).to(device))
+    out = three_interpolate(torch.from_numpy(z["feats"]).to(device), idx, w)
+    assert nerr(out, torch.from_numpy(z["out"])) < 2e-4
+    assert float((idx.cpu().sort(-1)[0] == torch.from_numpy(z["idx"]).sort(-1)[0]).float().mean()) > 0.99
+
+
 @pytest.mark.parametrize("method", ["HLT", "SAST", "Point_MAMBA"])
 def test_partseg_forward_matches_oracle_composition(method, device):
     from si_mamba_amd.seg import PartSegMamba, default_seg_config
