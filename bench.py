@@ -151,10 +151,11 @@ def main():
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
-    rank, world = sdist.init_dist("nccl" if args.gpus > 1 else None)
+    # RCCL ("nccl") over xGMI; SIMAMBA_DIST_BACKEND=gloo only to rehearse the N > 1 code path on a one-GPU box
+    rank, world = sdist.init_dist(os.environ.get("SIMAMBA_DIST_BACKEND", "nccl") if args.gpus > 1 else None)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count()
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
     _lib.load()
