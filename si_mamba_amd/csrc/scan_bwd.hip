@@ -79,8 +79,9 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_bwd_kernel(ScanArgs p) {
   float* sDf = sG + kRowsPerPass * p.passes * kMaxState;  // [16*passes] delta of the next chunk's first step
   float* sCk = sDf + kRowsPerPass * p.passes;             // [16 rows][kMaxState] chunk-start states of this pass
 
-  const int b = blockIdx.y;
-  const int tile_base = blockIdx.x * (kRowsPerPass * p.passes);
+  int tile_id, b;
+  xcd_tile(tile_id, b);
+  const int tile_base = tile_id * (kRowsPerPass * p.passes);
   const int lane16 = threadIdx.x & 15;
   const int rowslot = threadIdx.x >> 4;
   const int wave = threadIdx.x >> 6;

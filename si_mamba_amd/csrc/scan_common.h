@@ -18,6 +18,22 @@ namespace simamba {
 constexpr int kScanThreads = 256;
 constexpr int kRowsPerPass = kScanThreads / 16;  // 16 channels per workgroup pass
 constexpr int kMaxState = 16;
+constexpr int kNumXcd = 8;    // MI355X: 8 XCDs, each with its own 4 MB L2; workgroups are dealt to them round-robin
+
+// XCD-aware (tile, sample) of a workgroup in a (tiles, batch) grid.  The hardware sends consecutive workgroup
+// ids to consecutive XCDs, so with the plain blockIdx mapping the tiles of ONE sample -- which all read that
+// sample's B_t / C_t rows (and, in the backward, add into the same dB / dC rows) -- land on 8 different L2s.
+// Re-labelling id -> (id % 8) * (total / 8) + id / 8 makes the ids that one XCD receives a contiguous range of
+// (sample, tile) pairs: a sample's tiles share one L2.  Falls back to the identity when the grid does not
+// split evenly over the XCDs.
+__device__ __forceinline__ void xcd_tile(int& tile, int& sample) {
+  const int gx = gridDim.x;
+  const int total = gx * gridDim.y;
+  int id = blockIdx.y * gx + blockIdx.x;
+  if ((total % kNumXcd) == 0) id = (id % kNumXcd) * (total / kNumXcd) + id / kNumXcd;
+  sample = id / gx;
+  tile = id - sample * gx;
+}
 
 struct ScanArgs {
   const void* u;

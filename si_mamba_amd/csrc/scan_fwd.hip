@@ -18,8 +18,9 @@ __global__ __launch_bounds__(kScanThreads) void scan_fwd_kernel(ScanArgs p) {
   float* sCarry = sC + kMaxState * LDP;   // [16 * passes][kMaxState]
   float* sMid = sCarry + kRowsPerPass * p.passes * kMaxState;   // kItems == 16 only: state at the chunk's middle
 
-  const int b = blockIdx.y;
-  const int tile_base = blockIdx.x * (kRowsPerPass * p.passes);
+  int tile_id, b;
+  xcd_tile(tile_id, b);
+  const int tile_base = tile_id * (kRowsPerPass * p.passes);
   const int lane16 = threadIdx.x & 15;
   const int rowslot = threadIdx.x >> 4;   // 0..15: wave*4 + sub-row
   const int L = p.seqlen, D = p.dim, N = p.dstate;

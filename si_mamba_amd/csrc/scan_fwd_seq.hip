@@ -117,11 +117,12 @@ __global__ __launch_bounds__(kSeqThreads, SeqCfg<kLPC>::kWaves) void scan_fwd_se
   typedef SeqCfg<kLPC> Cfg;
   constexpr int NS = Cfg::NS, R = Cfg::R, kPacks = Cfg::kPacks;
   __shared__ __attribute__((aligned(16))) float sMem[kSeqThreads / 64][Cfg::kTileFloats];
-  const int b = blockIdx.y;
+  int tile_id, b;
+  xcd_tile(tile_id, b);
   const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);   // SGPR
   const int lane = threadIdx.x & 63;
   const int L = p.seqlen, D = p.dim;
-  const int ch_base = (blockIdx.x * (kSeqThreads / 64) + wave) * R;   // first channel of this wave
+  const int ch_base = (tile_id * (kSeqThreads / 64) + wave) * R;   // first channel of this wave
   if (ch_base >= D) return;                                            // whole wave idle (no barriers here)
   float* tD = &sMem[wave][0];
   float* tU = tD + R * kSeqTC;
