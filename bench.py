@@ -238,7 +238,16 @@ def main():
             out["kernels"] = {k: {"launches": v[0], "mean_ms": round(v[1], 4)} for k, v in ktimes.items()}
             if "scan_bwd" in ktimes:
                 bb = scan_bwd_bytes(args.batch, D, L, N, s)
-                out["kernels"]["scan_bwd"]["GB/s"] = round(bb / ktimes["scan_bwd"][1] / 1e6, 1)
+                nb, msb = ktimes["scan_bwd"]
+                out["kernels"]["scan_bwd"]["GB/s"] = round(bb / msb / 1e6, 1)
+                # the backward is the larger HIP kernel of the step by time: same accounting, for completeness
+                out["roofline_scan_bwd"] = {
+                    "bound": "hbm", "achieved": round(bb / msb / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(bb / msb / 1e6 / HBM_PEAK_GBS, 4),
+                    "traffic": traffic_from_profiles("scan_bwd", (args.batch, D, L, N)) if s == 4 else None,
+                    "kernel": f"scan_bwd_kernel<{'float' if s == 4 else 'bf16'},8>", "algorithmic_bytes": bb,
+                    "launches": nb, "mean_ms": round(msb, 4),
+                    "note": "VALU-bound (PMC: VALU 68 % busy at 2 waves/SIMD, 253 VGPRs); DESIGN.md 4.2"}
         if world == 1 and not args.no_headline:
             del opt
             torch.cuda.empty_cache()
