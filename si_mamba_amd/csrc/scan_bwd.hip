@@ -347,15 +347,32 @@ extern "C" int simamba_selective_scan_bwd(const void* u, const void* delta, cons
   if (nchunks > 1 && !x_ckpt) return SIMAMBA_E_NULLPTR;
   hipStream_t s = static_cast<hipStream_t>(stream);
   hipError_t e;
-  if ((e = hipMemsetAsync(dA, 0, sizeof(float) * dim * dstate, s)) != hipSuccess) return static_cast<int>(e);
-  const size_t bc = sizeof(float) * static_cast<size_t>(batch) * dstate * seqlen;
-  if (bc) {
-    if ((e = hipMemsetAsync(dB, 0, bc, s)) != hipSuccess) return static_cast<int>(e);
-    if ((e = hipMemsetAsync(dC, 0, bc, s)) != hipSuccess) return static_cast<int>(e);
+  // The five accumulators are zeroed here (the kernel adds into them).  When the caller carved them out of one
+  // allocation -- si_mamba_amd/mamba_inner.py does -- that is a single memset node instead of five.
+  {
+    const size_t bc = sizeof(float) * static_cast<size_t>(batch) * dstate * seqlen;
+    struct Span { char* p; size_t n; } sp[5] = {{reinterpret_cast<char*>(dA), sizeof(float) * dim * dstate},
+                                                 {reinterpret_cast<char*>(dB), bc},
+                                                 {reinterpret_cast<char*>(dC), bc},
+                                                 {reinterpret_cast<char*>(dD), dD ? sizeof(float) * dim : 0},
+                                                 {reinterpret_cast<char*>(ddelta_bias),
+                                                  ddelta_bias ? sizeof(float) * dim : 0}};
+    char* lo = nullptr;
+    char* hi = nullptr;
+    size_t total = 0;
+    for (const Span& x : sp) {
+      if (!x.n) continue;
+      lo = (!lo || x.p < lo) ? x.p : lo;
+      hi = (!hi || x.p + x.n > hi) ? x.p + x.n : hi;
+      total += x.n;
+    }
+    if (total && static_cast<size_t>(hi - lo) <= total + 5 * 256) {        // contiguous up to alignment padding
+      if ((e = hipMemsetAsync(lo, 0, static_cast<size_t>(hi - lo), s)) != hipSuccess) return static_cast<int>(e);
+    } else {
+      for (const Span& x : sp)
+        if (x.n && (e = hipMemsetAsync(x.p, 0, x.n, s)) != hipSuccess) return static_cast<int>(e);
+    }
   }
-  if (dD && (e = hipMemsetAsync(dD, 0, sizeof(float) * dim, s)) != hipSuccess) return static_cast<int>(e);
-  if (ddelta_bias && (e = hipMemsetAsync(ddelta_bias, 0, sizeof(float) * dim, s)) != hipSuccess)
-    return static_cast<int>(e);
   if (batch == 0 || seqlen == 0) return SIMAMBA_OK;
   ScanArgs a{};
   a.u = u; a.delta = delta; a.A = A; a.B = B; a.C = C; a.D = D; a.z = z; a.delta_bias = delta_bias;
