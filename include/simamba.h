@@ -192,7 +192,8 @@ int simamba_group_max_bwd(const void* dout, const unsigned char* idx, void* dx, 
  * to sum 1, and the weighted sum of the three centres' feature rows.
  *   xyz1 : (batch, N, 3) fp32 query points ; xyz2 : (batch, S, 3) fp32 centres ; idx : (batch, N, 3) int32 ;
  *   weight : (batch, N, 3) fp32 ; feats : (batch, S, C) io_dtype ; out : (batch, N, C) io_dtype ;
- *   dfeats : (batch, S, C) fp32, zeroed by the call, accumulated with float atomics.  C % 4 == 0, S <= 8192.
+ *   dfeats : (batch, S, C) fp32, every element written (deterministic gather, no atomics).  C % 4 == 0, S <= 8192,
+ *   N <= 8192 for the backward.
  */
 int simamba_three_nn(const float* xyz1, const float* xyz2, int* idx, float* weight, int batch, int N, int S,
                      void* stream);

@@ -9,8 +9,8 @@
 //     the lower centre index (the reference's sort leaves ties unspecified); writes idx (int32) and the
 //     normalised weights;
 //   * interp_fwd_kernel: out[b, n, :] = sum_k w_k feats[b, idx_k, :], 4 channels per lane, coalesced rows;
-//   * interp_bwd_kernel: dfeats[b, idx_k, :] += w_k dout[b, n, :] with float atomics (dfeats zeroed by the
-//     entry point); the three neighbours of a point are distinct rows, different points collide rarely.
+//   * interp_bwd_kernel: dfeats[b, s, :] = sum over the points that name centre s of w dout[b, n, :], as a
+//     deterministic gather (see the kernel).
 // HBM-bound: per sample N x C output floats + 3 gathered rows per point (L2-resident: S x C floats).
 #include "common.h"
 
@@ -95,27 +95,55 @@ __global__ __launch_bounds__(256) void interp_fwd_kernel(const T* __restrict__ f
   *reinterpret_cast<Pack<T, 4>*>(out + pt * C + c) = pk;
 }
 
+// Backward as a gather (deterministic, no atomics): one workgroup per (sample, centre).  Phase 1 scans the
+// sample's 3 N neighbour entries and compacts, in order, the (point, weight) pairs that name this centre into LDS
+// (wave ballots + a 4-entry prefix over the waves); phase 2 gives every lane 4 channels and sums
+// weight * dout[point] over that list with coalesced row reads.  Every dout row is read 3 times in total -- the
+// float-atomic scatter this replaces took 1.55 ms at (16, 2048, 1152) against 0.1 ms for the reads.
 template <typename T>
 __global__ __launch_bounds__(256) void interp_bwd_kernel(const T* __restrict__ dout, const int* __restrict__ idx,
                                                          const float* __restrict__ wgt, float* __restrict__ dfeats,
-                                                         long long points, int N, int S, int C) {
-  const int cq = C / 4;
-  const long long e = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (e >= points * cq) return;
-  const long long pt = e / cq;
-  const int c = static_cast<int>(e - pt * cq) * 4;
-  const long long b = pt / N;
-  const int* id = idx + pt * 3;
-  const float* w = wgt + pt * 3;
-  float d[4];
-  ld4<T>(dout + pt * C + c, d);
-  float* base = dfeats + b * S * C + c;
+                                                         int N, int S, int C) {
+  extern __shared__ int sm[];
+  int* sPt = sm;                                       // [N] point of each match
+  float* sWt = reinterpret_cast<float*>(sm + N);       // [N] its weight
+  __shared__ int sWave[4];
+  __shared__ int sBase;
+  const int s = blockIdx.x, b = blockIdx.y;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int* id = idx + static_cast<size_t>(b) * N * 3;
+  const float* w = wgt + static_cast<size_t>(b) * N * 3;
+  if (tid == 0) sBase = 0;
+  __syncthreads();
+  for (int base = 0; base < 3 * N; base += 256) {
+    const int e = base + tid;
+    const bool match = e < 3 * N && id[e] == s;
+    const unsigned long long bal = __ballot(match);
+    if (lane == 0) sWave[wave] = __popcll(bal);
+    __syncthreads();
+    int off = sBase;
+    for (int k = 0; k < wave; ++k) off += sWave[k];
+    if (match) {
+      const int pos = off + __popcll(bal & ((1ull << lane) - 1ull));
+      sPt[pos] = e / 3;
+      sWt[pos] = w[e];
+    }
+    __syncthreads();
+    if (tid == 0) sBase += sWave[0] + sWave[1] + sWave[2] + sWave[3];
+    __syncthreads();
+  }
+  const int count = sBase;
+  const T* drow = dout + static_cast<size_t>(b) * N * C;
+  float* orow = dfeats + (static_cast<size_t>(b) * S + s) * C;
+  for (int c = 4 * tid; c < C; c += 4 * 256) {
+    float acc[4] = {0.f, 0.f, 0.f, 0.f}, d[4];
+    for (int m = 0; m < count; ++m) {
+      ld4<T>(drow + static_cast<size_t>(sPt[m]) * C + c, d);
+      const float wk = sWt[m];
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const float wk = w[k];
-    float* dst = base + static_cast<long long>(id[k]) * C;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) atomicAdd(dst + i, wk * d[i]);
+      for (int i = 0; i < 4; ++i) acc[i] = fmaf(wk, d[i], acc[i]);
+    }
+    *reinterpret_cast<float4*>(orow + c) = make_float4(acc[0], acc[1], acc[2], acc[3]);
   }
 }
 
@@ -162,22 +190,22 @@ extern "C" int simamba_three_interpolate_fwd(const void* feats, const int* idx, 
 extern "C" int simamba_three_interpolate_bwd(const void* dout, const int* idx, const float* weight, float* dfeats,
                                              int batch, int N, int S, int C, int io_dtype, void* stream) {
   if (io_dtype != SIMAMBA_F32 && io_dtype != SIMAMBA_BF16) return SIMAMBA_E_DTYPE;
-  if (batch < 0 || N < 0 || S < 1 || C < 4 || (C % 4) != 0) return SIMAMBA_E_SHAPE;
+  if (batch < 0 || N < 0 || N > 8192 || S < 1 || S > 65535 || C < 4 || (C % 4) != 0 || batch > 65535)
+    return SIMAMBA_E_SHAPE;
   if (batch == 0) return SIMAMBA_OK;
   if (!dfeats) return SIMAMBA_E_NULLPTR;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const hipError_t e = hipMemsetAsync(dfeats, 0, sizeof(float) * static_cast<size_t>(batch) * S * C, s);
-  if (e != hipSuccess) return static_cast<int>(e);
-  if (N == 0) return SIMAMBA_OK;
+  if (N == 0) {
+    const hipError_t e = hipMemsetAsync(dfeats, 0, sizeof(float) * static_cast<size_t>(batch) * S * C, s);
+    return static_cast<int>(e);
+  }
   if (!dout || !idx || !weight) return SIMAMBA_E_NULLPTR;
-  const long long points = static_cast<long long>(batch) * N;
-  const long long total = points * (C / 4);
-  const dim3 grid(static_cast<unsigned>((total + 255) / 256));
+  const size_t smem = 8 * static_cast<size_t>(N);
   if (io_dtype == SIMAMBA_F32)
-    hipLaunchKernelGGL(interp_bwd_kernel<float>, grid, dim3(256), 0, s, static_cast<const float*>(dout), idx, weight,
-                       dfeats, points, N, S, C);
+    hipLaunchKernelGGL(interp_bwd_kernel<float>, dim3(S, batch), dim3(256), smem, s, static_cast<const float*>(dout), idx,
+                       weight, dfeats, N, S, C);
   else
-    hipLaunchKernelGGL(interp_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, static_cast<const bf16_t*>(dout), idx, weight,
-                       dfeats, points, N, S, C);
+    hipLaunchKernelGGL(interp_bwd_kernel<bf16_t>, dim3(S, batch), dim3(256), smem, s, static_cast<const bf16_t*>(dout),
+                       idx, weight, dfeats, N, S, C);
   return static_cast<int>(hipGetLastError());
 }

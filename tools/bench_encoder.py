@@ -34,3 +34,34 @@ for groups, n, C in [(8192, 32, 256), (8192, 32, 384)]:
     y = group_max_fn(x); dy = torch.randn_like(y)
     t = timeit(lambda: torch.autograd.grad(y, x, dy, retain_graph=True))
     print(f"group_max bwd: {t*1e3:7.1f} us  {mb/t/1e3:6.2f} TB/s;  torch max fwd {timeit(lambda: x.detach().max(dim=1)[0])*1e3:.1f} us")
+
+# ---- segmentation / pre-training head kernels ---------------------------------------------------------------
+from si_mamba_amd.interp import three_interpolate, three_nn
+from si_mamba_amd.mae import chamfer_distance
+from si_mamba_amd.grouping import knn_group, sample_farthest_points
+from si_mamba_amd.synthetic import make_clouds
+B, N, S, C = 16, 2048, 256, 1152
+pts = make_clouds(B, N, 0, dev)
+centres = pts[:, :S].contiguous()
+feats = torch.randn(B, S, C, device=dev, requires_grad=True)
+t = timeit(lambda: three_nn(pts, centres))
+print(f"three_nn ({B},{N}) x {S} centres: {t*1e3:7.1f} us")
+idx, w = three_nn(pts, centres)
+t = timeit(lambda: three_interpolate(feats.detach(), idx, w))
+mb = B * N * C * 4 / 1e6
+print(f"three_interpolate fwd -> ({B},{N},{C}): {t*1e3:7.1f} us  {mb/t/1e3:5.2f} TB/s of output bytes")
+out = three_interpolate(feats, idx, w); dout = torch.randn_like(out)
+t = timeit(lambda: torch.autograd.grad(out, feats, dout, retain_graph=True))
+print(f"three_interpolate bwd (gather): {t*1e3:7.1f} us  {mb/t/1e3:5.2f} TB/s of dout bytes")
+pairs = 64 * 304
+pred = torch.randn(pairs, 32, 3, device=dev, requires_grad=True); gt = torch.randn(pairs, 32, 3, device=dev)
+t = timeit(lambda: chamfer_distance(pred.detach(), gt))
+print(f"chamfer fwd {pairs} pairs of 32x32: {t*1e3:7.1f} us")
+d = chamfer_distance(pred, gt)
+t = timeit(lambda: torch.autograd.grad(d.sum(), pred, retain_graph=True))
+print(f"chamfer bwd: {t*1e3:7.1f} us")
+cl = make_clouds(64, 1024, 1, dev)
+cen, _ = sample_farthest_points(cl, 128)
+t = timeit(lambda: knn_group(cen, cl, 32))
+ref = timeit(lambda: torch.cdist(cen, cl).topk(32, dim=-1, largest=False, sorted=False)[1])
+print(f"knn_group (64,1024)->(64,128,32): {t*1e3:7.1f} us   (cdist + topk: {ref*1e3:.1f} us)")
