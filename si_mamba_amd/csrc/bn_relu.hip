@@ -328,22 +328,28 @@ __global__ void group_max_fwd_kernel(const T* __restrict__ x, T* __restrict__ ou
   *reinterpret_cast<uchar4*>(idx + g * C + c) = make_uchar4(bi[0], bi[1], bi[2], bi[3]);
 }
 
+// same (group, channel quad) -> lane map as the forward: a lane walks the n rows of its group and writes dout to the
+// arg-max row, zeros elsewhere (no per-element index arithmetic; the (group, row, quad) map of the first version
+// spent its time in 64-bit divisions and reached 2.6 TB/s)
 template <typename T>
 __global__ void group_max_bwd_kernel(const T* __restrict__ dout, const unsigned char* __restrict__ idx,
                                      T* __restrict__ dx, long long groups, int n, int C) {
-  const long long e = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;   // (group, row, channel quad)
+  const long long e = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;   // (group, channel quad)
   const int cq = C / 4;
-  if (e >= groups * n * cq) return;
-  const long long gr = e / cq;                       // group * n + row
-  const int c = static_cast<int>(e - gr * cq) * 4;
-  const long long g = gr / n;
-  const int r = static_cast<int>(gr - g * n);
-  float d[4], o[4];
+  if (e >= groups * cq) return;
+  const long long g = e / cq;
+  const int c = static_cast<int>(e - g * cq) * 4;
+  float d[4];
   load_c4<T>(dout + g * C + c, d);
   const uchar4 id = *reinterpret_cast<const uchar4*>(idx + g * C + c);
-  o[0] = id.x == r ? d[0] : 0.f; o[1] = id.y == r ? d[1] : 0.f;
-  o[2] = id.z == r ? d[2] : 0.f; o[3] = id.w == r ? d[3] : 0.f;
-  store_c4<T>(dx + gr * C + c, o);
+  T* base = dx + g * n * C + c;
+#pragma unroll 4
+  for (int r = 0; r < n; ++r) {
+    float o[4];
+    o[0] = id.x == r ? d[0] : 0.f; o[1] = id.y == r ? d[1] : 0.f;
+    o[2] = id.z == r ? d[2] : 0.f; o[3] = id.w == r ? d[3] : 0.f;
+    store_c4<T>(base + static_cast<long long>(r) * C, o);
+  }
 }
 
 static bool bn_shape_ok(long long rows, int C, long long ld, int group, bool has_g) {
@@ -459,7 +465,7 @@ extern "C" int simamba_group_max_bwd(const void* dout, const unsigned char* idx,
   if (groups < 0 || n < 1 || n > 256 || C < 4 || (C % 4) != 0) return SIMAMBA_E_SHAPE;
   if (!dout || !idx || !dx) return SIMAMBA_E_NULLPTR;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const long long total = groups * n * (C / 4);
+  const long long total = groups * (C / 4);
   if (total > 0x7fffffffll * 256) return SIMAMBA_E_SHAPE;
   const dim3 grid(static_cast<unsigned>((total + 255) / 256));
   if (io_dtype == SIMAMBA_F32)
