@@ -144,8 +144,10 @@ class PointMamba(nn.Module):
         self.alpha = config.alpha
         self.binary = config.binary
         self.matrix = config.matrix
-        if self.method != "SAST":
-            raise NotImplementedError("only the canonical SAST route is built (SURVEY.md headline 3)")
+        if self.method not in ("SAST", "HLT", "MAMBA"):
+            raise NotImplementedError(f"ordering method {self.method!r}: SAST (:868), HLT (:1054) and MAMBA (:850) "
+                                      "are built; the wavelet / RL research branches are out of scope")
+        self.hlt_rand = True          # the reference's torch.rand tie-break of HLT (:1062); tests switch it off
 
     def _side_stream(self, device):
         st = getattr(self, "_spectral_stream", None)
@@ -165,25 +167,43 @@ class PointMamba(nn.Module):
                                        smallest=self.smallest, symmetric=self.symmetric,
                                        self_loop=self.self_loop, binary=self.binary, matrix=self.matrix)[2]
 
+    def order_tokens(self, tokens, pos, center, order=None):
+        """Tokens and positions in sequence order for ``self.method`` (reference :850-1112)."""
+        if self.method == "SAST":                                               # :868-989
+            if order is None:
+                order = self.spectral_order(center)
+            return spectral.sast_gather(tokens, pos, order, reverse=self.reverse)
+        if self.method == "MAMBA":                                              # :850-866: x-, y-, z-sorted copies
+            idx = torch.cat([center[:, :, a].argsort(dim=-1) for a in range(3)], dim=1).unsqueeze(-1)
+            return (torch.gather(tokens, 1, idx.expand(-1, -1, tokens.shape[-1])),
+                    torch.gather(pos, 1, idx.expand(-1, -1, pos.shape[-1])))
+        # HLT :1054-1112
+        adj = spectral.create_graph_from_centers(center, self.knn_graph, self.alpha, self.symmetric, self.self_loop,
+                                                 self.binary)
+        vecs = spectral._eig(adj, self.k_top_eigenvectors, self.smallest, self.matrix != "laplacian", want_all=False)[1]
+        rand = torch.rand(center.shape[0], center.shape[1], device=center.device) if self.hlt_rand else None
+        t, p, _, _ = spectral.hlt_assemble(tokens, pos, center, vecs, self.k_top_eigenvectors, rand=rand)
+        return t, p
+
     def forward(self, pts, gt=None):
         neighborhood, center, _ = self.group_divider(pts)
+        order = None
+        overlap = center.is_cuda and self.method == "SAST"
         # The eigen-ordering depends only on the centres and is latency-bound on B of the 256 CUs: run it
         # on a side HIP stream underneath the (MFMA-bound) patch encoder, join before the gather.
-        if center.is_cuda:
+        if overlap:
             main = torch.cuda.current_stream(center.device)
             side = self._side_stream(center.device)
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 order = self.spectral_order(center)
             center.record_stream(side)
-        else:
-            order = self.spectral_order(center)
         tokens = self.encoder(neighborhood)
         pos = self.pos_embed(center)
-        if center.is_cuda:
+        if overlap:
             main.wait_stream(side)
             order.record_stream(main)
-        x, pos = spectral.sast_gather(tokens, pos, order, reverse=self.reverse)
+        x, pos = self.order_tokens(tokens, pos, center, order)
         x = self.drop_out(x)
         x = self.blocks(x, pos)
         x = self.norm(x)

@@ -154,3 +154,40 @@ def test_knn_group_matches_exact_neighbours(B, N, G, K, device):
         assert bool(same[clear].all()) and float(clear.float().mean()) > 0.9
     else:
         assert bool((idx.sort(-1)[0] == torch.arange(N)).all())
+
+
+@pytest.mark.parametrize("method", ["HLT", "MAMBA"])
+def test_pointmamba_other_orderings_match_oracle_composition(method, device):
+    """The classifier's HLT (:1054-1112) and MAMBA (:850-866) routes against the oracle's restatements."""
+    from si_mamba_amd.point_mamba import PointMamba, default_config
+    torch.manual_seed(0)
+    cfg = default_config(trans_dim=64, encoder_dims=64, depth=2, num_group=32, group_size=16, drop_path=0.,
+                         knn_graph=8, method=method, k_top_eigenvectors=3)
+    m = PointMamba(cfg).to(device).eval()
+    m.hlt_rand = False
+    pts = _clouds(3, 256, 4)
+    with torch.no_grad():
+        got = m(pts.to(device)).cpu()
+        nb, center, _ = m.group_divider(pts.to(device))
+        tokens, pos = m.encoder(nb).cpu(), m.pos_embed(center).cpu()
+        center = center.cpu()
+    if method == "HLT":
+        adj = sr.create_graph_from_centers(center, 8, cfg.alpha, True, False, True)
+        _, vecs, _, _ = sr.calc_top_k_eigenvalues_eigenvectors(adj, 3, True)
+        idx = vecs.abs().argmax(dim=1, keepdim=True)
+        vecs = vecs * torch.sign(torch.gather(vecs, 1, idx))                 # the device solver's sign convention
+        x, p, _, _ = sr.hlt_order_and_assemble(tokens, pos, center, vecs, 3)
+    else:
+        ids = [center[:, :, a].argsort(dim=-1)[:, :, None] for a in range(3)]
+        x = torch.cat([tokens.gather(1, torch.tile(i, (1, 1, tokens.shape[-1]))) for i in ids], dim=1)
+        p = torch.cat([pos.gather(1, torch.tile(i, (1, 1, pos.shape[-1]))) for i in ids], dim=1)
+    h, res = x + p, None
+    cpu = m.cpu()
+    with torch.no_grad():
+        for layer in cpu.blocks.layers:
+            r = scan_ref.MambaRef(64)
+            r.load_state_dict(layer.mixer.state_dict())
+            res = h if res is None else h + res
+            h = r(layer.norm(res))
+        want = cpu.cls_head_finetune(cpu.norm(cpu.blocks.norm_f(h + res)).mean(1))
+    assert (got - want).abs().max() < 2e-3 * max(1.0, want.abs().max().item())
