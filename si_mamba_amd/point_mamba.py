@@ -180,7 +180,7 @@ class PointMamba(nn.Module):
         # HLT :1054-1112
         adj = spectral.create_graph_from_centers(center, self.knn_graph, self.alpha, self.symmetric, self.self_loop,
                                                  self.binary)
-        vecs = spectral._eig(adj, self.k_top_eigenvectors, self.smallest, self.matrix != "laplacian", want_all=False)[1]
+        vecs = spectral._eig(adj, self.k_top_eigenvectors, self.smallest, False, want_all=False)[1]     # :1057
         rand = torch.rand(center.shape[0], center.shape[1], device=center.device) if self.hlt_rand else None
         t, p, _, _ = spectral.hlt_assemble(tokens, pos, center, vecs, self.k_top_eigenvectors, rand=rand)
         return t, p
