@@ -1,7 +1,7 @@
-"""Caller of the hot path: the reference's ``PointMamba`` classifier, canonical SAST route.
+"""Caller of the hot path: the reference's ``PointMamba`` classifier.
 
 Mirrors reference models/point_mamba.py ``PointMamba`` (:431-562 constructor, :843-1125 forward with
-``method == "SAST"``, ``use_wavelets=False``, ``tau=None``) with the parameter names and shapes of the
+``method`` in {"SAST" (canonical), "HLT", "MAMBA"}, ``use_wavelets=False``, ``tau=None``) with the parameter names and shapes of the
 reference's own checkpoint table (logs/finetuned_hardest.log:100-426, 12.29 M parameters), so a
 reference state_dict loads unchanged.  What runs on the HIP kernels: the spectral ordering
 (``spectral.spectral_order``) and every Mamba mixer of ``blocks``.
