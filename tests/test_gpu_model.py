@@ -191,3 +191,21 @@ def test_pointmamba_other_orderings_match_oracle_composition(method, device):
             h = r(layer.norm(res))
         want = cpu.cls_head_finetune(cpu.norm(cpu.blocks.norm_f(h + res)).mean(1))
     assert (got - want).abs().max() < 2e-3 * max(1.0, want.abs().max().item())
+
+
+def test_pytorch3d_shim_call_forms(device):
+    """install_shim(pytorch3d=True): the reference's three pytorch3d calls, in its argument forms."""
+    import si_mamba_amd
+    si_mamba_amd.install_shim(pytorch3d=True)
+    from pytorch3d.loss import chamfer_distance
+    from pytorch3d.ops import knn_points, sample_farthest_points
+    xyz = _clouds(2, 512, 9).to(device)
+    center = sample_farthest_points(points=xyz, K=32)[0]                       # models/point_mamba.py:93-94
+    idx = knn_points(center, xyz, K=16, return_sorted=False).idx               # :96-97
+    assert center.shape == (2, 32, 3) and idx.shape == (2, 32, 16) and idx.dtype == torch.int64
+    want = torch.cdist(center.double(), xyz.double()).topk(16, dim=-1, largest=False)[1].sort(-1)[0]
+    assert float((idx.sort(-1)[0] == want).float().mean()) > 0.99
+    a, b = torch.randn(7, 32, 3, device=device), torch.randn(7, 32, 3, device=device)
+    d = chamfer_distance(a, b, batch_reduction=None)[0]                        # :3203
+    ref = ((a.unsqueeze(2) - b.unsqueeze(1)) ** 2).sum(-1)
+    assert torch.allclose(d, ref.min(2)[0].mean(1) + ref.min(1)[0].mean(1), rtol=1e-5, atol=1e-6)
