@@ -159,6 +159,8 @@ class MaskMamba_2(nn.Module):
             mask = (self._mask_center_rand if self.mask_type == "rand" else self._mask_center_block)(center, noaug)
         tokens = self.encoder(neighborhood)
         pos = self.pos_embed(center)
+        if callable(orders):                       # still in flight on the side stream (Point_MAE_Mamba.forward)
+            orders = orders()
         C = tokens.shape[-1]
         k = orders.shape[1]
         vis_pos, msk_pos, smask = masked_positions(orders, mask)
@@ -175,7 +177,7 @@ class MaskMamba_2(nn.Module):
 
         x_vis = self.blocks(take(tokens, vis_src), take(pos, vis_src))
         x_vis = self.norm(x_vis)
-        return dict(x_vis=x_vis, pos_mask=take(pos, msk_src), pos_full=take(pos, full_src), mask=mask,
+        return dict(x_vis=x_vis, orders=orders, pos_mask=take(pos, msk_src), pos_full=take(pos, full_src), mask=mask,
                     sorted_mask=smask, vis_seq=sequence_positions(vis_pos, G, reverse),
                     msk_seq=sequence_positions(msk_pos, G, reverse), msk_src=msk_src, C=C)
 
@@ -248,9 +250,11 @@ class Point_MAE_Mamba(nn.Module):
         neighborhood, center, _ = self.group_divider(pts)
         B, G, M, _ = neighborhood.shape
         if orders is None:
-            orders = self.spectral_orders(center)
-        k = orders.shape[1]
+            # the eigen-ordering only needs the centres: it runs on a side stream underneath the patch encoder
+            orders = spectral.run_on_side_stream(lambda: self.spectral_orders(center), center)
         enc = self.MAE_encoder(neighborhood, center, orders, self.reverse, noaug, mask=mask)
+        orders = enc["orders"]
+        k = orders.shape[1]
         x_vis, C = enc["x_vis"], enc["C"]
         if noaug:
             return x_vis
@@ -267,5 +271,5 @@ class Point_MAE_Mamba(nn.Module):
         gt = gt.reshape(B * Mtok, M, 3)
         loss = chamfer_distance(rebuild.float(), gt.float()).mean()
         if return_parts:
-            return loss, dict(enc, rebuild=rebuild, gt=gt, x_full=x_full, orders=orders)
+            return loss, dict(enc, rebuild=rebuild, gt=gt, x_full=x_full)
         return loss

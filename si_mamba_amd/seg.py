@@ -164,7 +164,18 @@ class PartSegMamba(nn.Module):
         self.hlt_rand = True          # the reference's torch.rand tie-break (:655); tests switch it off
 
     # ---- token ordering ------------------------------------------------------------------------------------------
-    def order_tokens(self, tokens, pos, center):
+    def _spectral(self, center):
+        """What the ordering needs from the eigen-solver: eigenvectors (HLT) or the k argsorts (SAST); None otherwise.
+        Depends on the centres only, so forward() runs it on a side stream underneath the patch encoder."""
+        if self.method == "Point_MAMBA":
+            return None
+        adj = spectral.create_graph_from_centers(center, self.knn_graph, self.alpha, self.symmetric, self.self_loop,
+                                                 self.binary)
+        if self.method == "HLT":                                                # :667-668
+            return spectral._eig(adj, self.k_top_eigenvectors, self.smallest, False, want_all=False)[1]
+        return spectral._eig(adj, self.k_top_eigenvectors, self.smallest, False, want_all=False, want_order=True)[4]
+
+    def order_tokens(self, tokens, pos, center, spec=None):
         """-> (tokens, pos, center) in sequence order: (B, L, C), (B, L, C), (B, L, 3)."""
         if self.method == "Point_MAMBA":                                        # :640-663
             idx = torch.cat([center[:, :, a].argsort(dim=-1) for a in range(3)], dim=1)
@@ -172,18 +183,14 @@ class PartSegMamba(nn.Module):
             return (torch.gather(tokens, 1, ex.expand(-1, -1, tokens.shape[-1])),
                     torch.gather(pos, 1, ex.expand(-1, -1, pos.shape[-1])),
                     torch.gather(center, 1, ex.expand(-1, -1, 3)))
+        if spec is None:
+            spec = self._spectral(center)
         if self.method == "HLT":                                                # :665-723
-            adj = spectral.create_graph_from_centers(center, self.knn_graph, self.alpha, self.symmetric,
-                                                     self.self_loop, self.binary)
-            vecs = spectral._eig(adj, self.k_top_eigenvectors, self.smallest, False, want_all=False)[1]
             rand = torch.rand(center.shape[0], center.shape[1], device=center.device) if self.hlt_rand else None
-            t, p, c, _ = spectral.hlt_assemble(tokens, pos, center, vecs, self.k_top_eigenvectors, rand=rand)
+            t, p, c, _ = spectral.hlt_assemble(tokens, pos, center, spec, self.k_top_eigenvectors, rand=rand)
             return t, p, c
         # SAST :725-759 (the graph is create_graph_from_centers here, not the feature-space variant)
-        adj = spectral.create_graph_from_centers(center, self.knn_graph, self.alpha, self.symmetric, self.self_loop,
-                                                 self.binary)
-        order = spectral._eig(adj, self.k_top_eigenvectors, self.smallest, False, want_all=False, want_order=True)[4]
-        idx = spectral.sast_index_map(order, self.reverse)
+        idx = spectral.sast_index_map(spec, self.reverse)
         ex = idx.unsqueeze(-1)
         return (torch.gather(tokens, 1, ex.expand(-1, -1, tokens.shape[-1])),
                 torch.gather(pos, 1, ex.expand(-1, -1, pos.shape[-1])),
@@ -194,9 +201,10 @@ class PartSegMamba(nn.Module):
         B, _, N = pts.shape
         pts = pts.transpose(-1, -2).contiguous()                                # (B, N, 3)
         neighborhood, center, _ = self.group_divider(pts)
+        spec = spectral.run_on_side_stream(lambda: self._spectral(center), center)
         tokens = self.encoder(neighborhood)
         pos = self.pos_embed(center)
-        x, spos, scenter = self.order_tokens(tokens, pos, center)
+        x, spos, scenter = self.order_tokens(tokens, pos, center, spec())
         feats = self.blocks(x, spos)
         feats = torch.cat([self.norm(f) for f in feats], dim=-1)                # (B, L, 1152)
         x_max = feats.max(dim=1)[0]

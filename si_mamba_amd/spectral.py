@@ -208,6 +208,38 @@ def hlt_assemble(tokens, pos, center, top_k_eigenvectors, k, rand=None):
     return pick(tokens), pick(pos), pick(center), order
 
 
+_side_streams = {}
+
+
+def run_on_side_stream(fn, *inputs):
+    """Start ``fn()`` on a side HIP stream (one per device, created on first use) and return a ``join()`` that makes
+    the current stream wait for it and hands back its result.  The eigen-ordering kernels occupy B of the 256 CUs
+    and depend only on the patch centres, so callers launch them underneath the (GEMM-bound) patch encoder.
+    ``inputs``: the tensors ``fn`` reads (kept alive for the side stream).  CPU tensors: runs inline."""
+    if not inputs or not inputs[0].is_cuda:
+        res = fn()
+        return lambda: res
+    dev = inputs[0].device
+    main = torch.cuda.current_stream(dev)
+    side = _side_streams.get(dev)
+    if side is None:
+        side = _side_streams[dev] = torch.cuda.Stream(device=dev)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        res = fn()
+    for t in inputs:
+        t.record_stream(side)
+
+    def join():
+        cur = torch.cuda.current_stream(dev)
+        cur.wait_stream(side)
+        for r in (res if isinstance(res, (tuple, list)) else (res,)):
+            if torch.is_tensor(r):
+                r.record_stream(cur)
+        return res
+    return join
+
+
 def bind_to(cls):
     """Monkey-patch the spectral methods of a reference-style PointMamba class with these kernels."""
     def _m(fn):
