@@ -62,5 +62,7 @@ def wrap_ddp(model, device=None, bucket_cap_mb: int = 64):
         return model                      # plain single-process run: nothing to synchronise
     from torch.nn.parallel import DistributedDataParallel as DDP
     ids = None if device is None or device.type != "cuda" else [device.index]
+    # broadcast_buffers=True is DDP's default and what the reference gets (tools/runner_finetune.py:124-125):
+    # BatchNorm running statistics follow rank 0 (a few KB per step)
     return DDP(model, device_ids=ids, bucket_cap_mb=bucket_cap_mb, gradient_as_bucket_view=True,
-               static_graph=True, broadcast_buffers=False)
+               static_graph=True, broadcast_buffers=True)
