@@ -82,11 +82,13 @@ def chamfer_distance(pred, gt):
 
 
 # ---- index arithmetic shared by encoder and decoder ---------------------------------------------------------------
-def masked_positions(orders, mask):
-    """orders (B,k,G) int64, mask (B,G) bool with the same number of True per row ->
+def masked_positions(orders, mask, nm=None):
+    """orders (B,k,G) int64, mask (B,G) bool with the same number ``nm`` of True per row (pass it to avoid a host
+    read-back) ->
     vis_pos (B,k,G-nm), msk_pos (B,k,nm): positions inside each ordered sequence, ascending."""
     smask = torch.gather(mask.unsqueeze(1).expand(-1, orders.shape[1], -1), 2, orders)        # (B,k,G)
-    nm = int(mask[0].sum())
+    if nm is None:
+        nm = int(mask[0].sum())                                                                  # host sync
     pos = torch.sort(smask.to(torch.uint8), dim=2, stable=True)[1]                               # False first
     G = orders.shape[2]
     return pos[:, :, :G - nm], pos[:, :, G - nm:], smask
@@ -155,6 +157,7 @@ class MaskMamba_2(nn.Module):
     def forward(self, neighborhood, center, orders, reverse=True, noaug=False, mask=None):
         """-> dict with x_vis (B, n_vis_tokens, C) after blocks + norm and the index tensors the decoder needs."""
         B, G, _ = center.shape
+        user_mask = mask is not None
         if mask is None:
             mask = (self._mask_center_rand if self.mask_type == "rand" else self._mask_center_block)(center, noaug)
         tokens = self.encoder(neighborhood)
@@ -163,7 +166,10 @@ class MaskMamba_2(nn.Module):
             orders = orders()
         C = tokens.shape[-1]
         k = orders.shape[1]
-        vis_pos, msk_pos, smask = masked_positions(orders, mask)
+        # number of masked patches per cloud: known on the host for the generated masks (no device read-back, so the
+        # step stays capturable in a hipGraph); counted only for caller-supplied masks
+        nm = None if user_mask else (0 if (noaug or self.mask_ratio == 0) else int(self.mask_ratio * G))
+        vis_pos, msk_pos, smask = masked_positions(orders, mask, nm)
         vis_src = torch.gather(orders, 2, vis_pos).reshape(B, -1)                  # patch ids, visible, by ordering
         msk_src = torch.gather(orders, 2, msk_pos).reshape(B, -1)
         full_src = orders.reshape(B, k * G)

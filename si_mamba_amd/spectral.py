@@ -164,6 +164,9 @@ def sast_gather(tokens, pos, order, reverse=True):
             torch.gather(pos, 1, ex.expand(-1, -1, pos.shape[-1])))
 
 
+_hlt_maps = {}
+
+
 def hlt_index_map(G, k, device=None):
     """Source position (into the code-sorted sequence of G patches) of each of the 2G output slots of the
     reference's HLT assembly (:1075-1112, reverse == True), -1 where the reference leaves zeros.
@@ -172,6 +175,9 @@ def hlt_index_map(G, k, device=None):
     into block i+2 (block 1 for i == 0); later writes overwrite earlier ones.  Replaying those assignments on
     an index vector gives the same result as its slice assignments, in one gather.
     """
+    key = (G, k, None if device is None else str(device))
+    if key in _hlt_maps:                      # built once per shape and device: no host-to-device copy per call
+        return _hlt_maps[key]                 # (and none inside a hipGraph capture)
     ng = 2 ** k
     nd = G // ng
     idx = torch.full((2 * G,), -1, dtype=torch.int64)
@@ -183,7 +189,9 @@ def hlt_index_map(G, k, device=None):
             idx[d0:d0 + ng] = src
         if r0 + ng <= 2 * G:
             idx[r0:r0 + ng] = src.flip(0)
-    return idx if device is None else idx.to(device)
+    idx = idx if device is None else idx.to(device)
+    _hlt_maps[key] = idx
+    return idx
 
 
 def hlt_assemble(tokens, pos, center, top_k_eigenvectors, k, rand=None):

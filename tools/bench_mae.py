@@ -11,12 +11,13 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--dtype", default="bf16")
 ap.add_argument("--steps", type=int, default=8)
+ap.add_argument("--graph", action="store_true", help="capture the whole step in one hipGraph (GraphedTrainStep)")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 m = Point_MAE_Mamba(default_mae_config()).to(dev).train()
 params = [p for k, p in m.named_parameters() if not k.startswith("decoder_pos_embed.")]
-opt = torch.optim.AdamW(params, lr=1e-3, weight_decay=0.05, fused=True)
+opt = torch.optim.AdamW(params, lr=1e-3, weight_decay=0.05, fused=True, capturable=args.graph)
 pts = make_clouds(args.batch, 1024, 0).to(dev)
 amp = torch.autocast("cuda", dtype=torch.bfloat16, enabled=args.dtype == "bf16")
 
@@ -29,6 +30,14 @@ def step():
     opt.step()
     return loss
 
+if args.graph:
+    from si_mamba_amd.graphed import GraphedTrainStep
+
+    def loss_fn(p):
+        with amp:
+            return m(p)
+    gstep = GraphedTrainStep(loss_fn, opt, (pts,), params=params, clip=10.0)
+    step = lambda: gstep(pts)
 for _ in range(3):
     step()
 torch.cuda.synchronize()
@@ -37,5 +46,5 @@ for _ in range(args.steps):
     loss = step()
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / args.steps
-print(json.dumps({"workload": f"MAE pre-train step, B={args.batch}, 1024 pts -> 64 patches, {args.dtype}",
+print(json.dumps({"workload": f"MAE pre-train step, B={args.batch}, 1024 pts -> 64 patches, {args.dtype}" + (", hipGraph" if args.graph else ""),
                   "ms_per_step": round(dt * 1e3, 2), "clouds_per_s": round(args.batch / dt, 1), "loss": float(loss)}))

@@ -12,11 +12,12 @@ ap.add_argument("--npoints", type=int, default=2048)
 ap.add_argument("--method", default="HLT")
 ap.add_argument("--dtype", default="bf16")
 ap.add_argument("--steps", type=int, default=8)
+ap.add_argument("--graph", action="store_true", help="capture the whole step in one hipGraph (GraphedTrainStep)")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 m = PartSegMamba(50, default_seg_config(method=args.method)).to(dev).train()
-opt = torch.optim.AdamW(m.parameters(), lr=2e-4, weight_decay=0.05, fused=True)
+opt = torch.optim.AdamW(m.parameters(), lr=2e-4, weight_decay=0.05, fused=True, capturable=args.graph)
 pts = make_clouds(args.batch, args.npoints, 0).to(dev).transpose(1, 2).contiguous()
 label = torch.nn.functional.one_hot(torch.randint(0, 16, (args.batch,)), 16).float().to(dev)
 target = torch.randint(0, 50, (args.batch, args.npoints), device=dev)
@@ -32,6 +33,15 @@ def step():
     opt.step()
     return loss
 
+if args.graph:
+    from si_mamba_amd.graphed import GraphedTrainStep
+
+    def loss_fn(p, lab, tgt):
+        with amp:
+            out = m(p, lab)
+        return crit(out.reshape(-1, 50), tgt.view(-1))
+    gstep = GraphedTrainStep(loss_fn, opt, (pts, label, target))
+    step = lambda: gstep(pts, label, target)
 for _ in range(3):
     step()
 torch.cuda.synchronize()
@@ -40,5 +50,5 @@ for _ in range(args.steps):
     loss = step()
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / args.steps
-print(json.dumps({"workload": f"part segmentation train step, {args.method}, {args.npoints} pts, B={args.batch}, {args.dtype}",
+print(json.dumps({"workload": f"part segmentation train step, {args.method}, {args.npoints} pts, B={args.batch}, {args.dtype}" + (", hipGraph" if args.graph else ""),
                   "ms_per_step": round(dt * 1e3, 2), "clouds_per_s": round(args.batch / dt, 1), "loss": float(loss)}))
