@@ -53,10 +53,12 @@ class InProjFn(torch.autograd.Function):
         if torch.is_autocast_enabled("cuda"):
             io = torch.get_autocast_dtype("cuda")
             hidden = hidden.to(io)
-        xz = _wx(_w(weight, io), hidden.transpose(1, 2))
+        wc = _w(weight, io)
+        xz = _wx(wc, hidden.transpose(1, 2))
         if bias is not None:
             xz = xz + _w(bias, io)[None, :, None]
         ctx.save_for_backward(hidden, weight)
+        ctx.wc = wc                     # the weight in compute dtype: not cast a second time in backward
         ctx.has_bias = bias is not None
         return xz
 
@@ -65,7 +67,7 @@ class InProjFn(torch.autograd.Function):
         hidden, weight = ctx.saved_tensors
         io = hidden.dtype
         dxz = dxz.to(io)
-        dh = _xw(dxz.transpose(1, 2), _w(weight, io)) if ctx.needs_input_grad[0] else None   # (B, L, d)
+        dh = _xw(dxz.transpose(1, 2), ctx.wc) if ctx.needs_input_grad[0] else None            # (B, L, d)
         dw = _sum_bmm(dxz, hidden).to(weight.dtype) if ctx.needs_input_grad[1] else None     # (2D, d)
         db = dxz.sum((0, 2)).to(weight.dtype) if ctx.has_bias else None
         return dh, dw, db
@@ -107,8 +109,10 @@ class MambaInnerFn(torch.autograd.Function):
                                                Bsz, Dm, L, W, 1, code, xbs, stream)
         _lib.check(rc, "simamba_causal_conv1d_fwd")
 
-        x_dbl = _xw(x_conv.transpose(1, 2), _w(x_proj_w, io).t())                      # (B, L, S)
-        delta = _wx(_w(dt_proj_w, io), x_dbl[:, :, :R].transpose(1, 2))                # (B, D, L)
+        xw_c, dtw_c, ow_c = _w(x_proj_w, io), _w(dt_proj_w, io), _w(out_proj_w, io)   # compute-dtype weights,
+        ctx.wcast = (xw_c, dtw_c, ow_c)                                               # reused by backward
+        x_dbl = _xw(x_conv.transpose(1, 2), xw_c.t())                                  # (B, L, S)
+        delta = _wx(dtw_c, x_dbl[:, :, :R].transpose(1, 2))                            # (B, D, L)
         Bv, Cv = x_dbl[:, :, R:R + N], x_dbl[:, :, R + N:]                            # (B, L, N) views
 
         nchunks = lib.simamba_scan_num_chunks(L)
@@ -125,7 +129,7 @@ class MambaInnerFn(torch.autograd.Function):
                 _lib.ptr(ws), 0 if ws is None else ws.numel(), stream)
         _lib.check(rc, "simamba_selective_scan_fwd")
 
-        out = _xw(y.transpose(1, 2), _w(out_proj_w, io).t())                           # (B, L, d)
+        out = _xw(y.transpose(1, 2), ow_c.t())                                         # (B, L, d)
         if out_proj_b is not None:
             out = out + _w(out_proj_b, io)
         ctx.dims = (R, N, W)
@@ -158,7 +162,8 @@ class MambaInnerFn(torch.autograd.Function):
         # out_proj
         d_out_w = _sum_bmm(dout.transpose(1, 2), y.transpose(1, 2))                   # (d, D)
         d_out_b = dout.sum((0, 1)) if ctx.has_out_bias else None
-        dy = _wx(_w(out_proj_w, io).t(), dout.transpose(1, 2))                        # (B, D, L)
+        xw_c, dtw_c, ow_c = ctx.wcast
+        dy = _wx(ow_c.t(), dout.transpose(1, 2))                                      # (B, D, L)
 
         # selective scan
         dxz = torch.empty_like(xz)
@@ -190,13 +195,13 @@ class MambaInnerFn(torch.autograd.Function):
 
         # dt_proj / x_proj
         dx_dbl = torch.empty(Bsz, L, S, device=dev, dtype=io)
-        dx_dbl[:, :, :R].copy_(_xw(ddelta.transpose(1, 2), _w(dt_proj_w, io)))
+        dx_dbl[:, :, :R].copy_(_xw(ddelta.transpose(1, 2), dtw_c))
         dx_dbl[:, :, R:R + N].copy_(dB.transpose(1, 2))
         dx_dbl[:, :, R + N:].copy_(dC.transpose(1, 2))
         d_dt_w = _sum_bmm(ddelta, x_dbl[:, :, :R])                                     # (D, R)
         d_x_w = _sum_bmm(dx_dbl.transpose(1, 2), x_conv.transpose(1, 2))               # (S, D)
         # dx_conv = du + x_proj_w^T @ dx_dbl^T, accumulated in place by the GEMM (beta = 1)
-        wxT = _w(x_proj_w, io).t().unsqueeze(0).expand(Bsz, -1, -1)
+        wxT = xw_c.t().unsqueeze(0).expand(Bsz, -1, -1)
         torch.baddbmm(du, wxT, dx_dbl.transpose(1, 2), out=du)
 
         # conv1d: dx goes straight into the first half of dxz
