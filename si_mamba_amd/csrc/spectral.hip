@@ -41,28 +41,45 @@ __global__ void dist_sum_kernel(const float* __restrict__ pts, double* __restric
 }
 
 // ---------------------------------------------------------------------------------------------
-// k-NN adjacency of one sample per workgroup.  One lane per graph node: its row of the distance matrix
-// lives in registers (the state loop is unrolled, so every access is statically indexed), the knn+1
-// selection passes are pure VALU compare/select sweeps over those registers (the first version swept an
-// LDS copy of the matrix: 21 x 128 dependent LDS reads per lane, 0.64 ms per batch), the picked
-// (index, weight) lists go to LDS once and feed both index_put phases of the reference.
+// k-NN adjacency of one sample per workgroup.  FOUR lanes (one quad) per graph node: lane p of the quad keeps the
+// distances to nodes p, p + 4, p + 8, ... in 32 registers (the loops are unrolled, every access is statically
+// indexed); each of the knn+1 selection passes is a compare/select sweep over those registers followed by a
+// two-step DPP quad reduction of the (value, index) pair, lexicographic so that ties go to the lower index like
+// a stable sort.  The picked (index, weight) lists go to LDS once and feed both index_put phases of the
+// reference.  (History: sweeping an LDS copy of the matrix cost 0.64 ms per batch of 64; one lane per node with
+// 128 registers 0.32 ms -- two waves per CU are latency-bound.)
 constexpr int kKnnMaxK = 32;   // knn + 1 <= 32 list entries per node
+constexpr int kKnnLanes = 4;   // lanes per node
+constexpr int kKnnPer = kSpecMaxG / kKnnLanes;   // distances per lane
 
-__global__ __launch_bounds__(kSpecMaxG) void knn_graph_kernel(const float* __restrict__ pts,
-                                                               float* __restrict__ adj,
-                                                               const double* __restrict__ dist_sum, int B,
-                                                               int G, int F, int knn, float alpha,
-                                                               unsigned flags) {
+// lexicographic (value, index) minimum over the 4 lanes of a quad, result in every lane
+__device__ __forceinline__ void quad_argmin(float& v, int& i) {
+#pragma unroll
+  for (int step = 0; step < 2; ++step) {
+    const float ov = step == 0 ? dpp<DPP_QUAD_XOR1>(v, v) : dpp<DPP_QUAD_XOR2>(v, v);
+    const int oi = step == 0 ? __builtin_amdgcn_update_dpp(i, i, DPP_QUAD_XOR1, 0xf, 0xf, false)
+                             : __builtin_amdgcn_update_dpp(i, i, DPP_QUAD_XOR2, 0xf, 0xf, false);
+    const bool take = (ov < v) || (ov == v && static_cast<unsigned>(oi) < static_cast<unsigned>(i));
+    v = take ? ov : v;
+    i = take ? oi : i;
+  }
+}
+
+__global__ __launch_bounds__(kSpecMaxG * kKnnLanes) void knn_graph_kernel(const float* __restrict__ pts,
+                                                                            float* __restrict__ adj,
+                                                                            const double* __restrict__ dist_sum,
+                                                                            int B, int G, int F, int knn, float alpha,
+                                                                            unsigned flags) {
   extern __shared__ float sm[];
   float* sAdj = sm;                                   // [G][G+1]
   float* sP = sAdj + G * (G + 1);                     // [G][F]
   float* sWt = sP + G * F;                            // [G][kKnnMaxK]
   int* sNb = reinterpret_cast<int*>(sWt + G * kKnnMaxK);   // [G][kKnnMaxK]
   const int LD = G + 1;
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, nthr = blockDim.x;
   const float* P = pts + static_cast<size_t>(blockIdx.x) * G * F;
-  for (int e = tid; e < G * F; e += kSpecMaxG) sP[e] = P[e];
-  for (int e = tid; e < G * LD; e += kSpecMaxG) sAdj[e] = 0.f;
+  for (int e = tid; e < G * F; e += nthr) sP[e] = P[e];
+  for (int e = tid; e < G * LD; e += nthr) sAdj[e] = 0.f;
   __syncthreads();
   const bool self_loop = flags & SIMAMBA_SPEC_SELF_LOOP;
   const bool binary = flags & SIMAMBA_SPEC_BINARY;
@@ -72,60 +89,68 @@ __global__ __launch_bounds__(kSpecMaxG) void knn_graph_kernel(const float* __res
     const float sigma = static_cast<float>(*dist_sum / (static_cast<double>(B) * G * G));
     inv2s2 = 2.f * (sigma * sigma);
   }
+  const int i = tid >> 2, part = tid & 3;             // node, lane of its quad (blockDim = 4 G: every quad is whole)
   int nlist = 0;
-  if (tid < G) {
-    const int i = tid;
-    float d[kSpecMaxG];
+  {
+    float d[kKnnPer];
 #pragma unroll
-    for (int j = 0; j < kSpecMaxG; ++j) {
+    for (int jj = 0; jj < kKnnPer; ++jj) {
+      const int j = part + kKnnLanes * jj;
       float d2 = 0.f;
       if (j < G) {
         for (int f = 0; f < F; ++f) {
           const float df = sP[i * F + f] - sP[j * F + f];
           d2 = d2 + df * df;
         }
-        d[j] = sqrtf(d2);
+        d[jj] = sqrtf(d2);
       } else {
-        d[j] = __builtin_inff();
+        d[jj] = __builtin_inff();
       }
     }
     float pv = -1.f;   // previous pick, ascending lexicographic (value, index) order
     int pi = -1;
     for (int m = 0; m <= knn; ++m) {
       float bv = 3.0e38f;
-      int bi = -1;
+      int bi = 0x7fffffff;
 #pragma unroll
-      for (int j = 0; j < kSpecMaxG; ++j) {
-        const float v = d[j];
+      for (int jj = 0; jj < kKnnPer; ++jj) {
+        const float v = d[jj];
+        const int j = part + kKnnLanes * jj;
         const bool after_prev = (v > pv) || (v == pv && j > pi);
-        if (after_prev && (v < bv)) { bv = v; bi = j; }
+        if (after_prev && (v < bv)) { bv = v; bi = j; }     // ascending j inside the lane: first hit is the lowest
       }
+      quad_argmin(bv, bi);
       pv = bv; pi = bi;
-      if (bi < 0) break;                       // NaN distances: nothing left to pick
+      if (bi == 0x7fffffff) break;             // NaN distances: nothing left to pick (quad-uniform)
       if (m == 0 && !self_loop) continue;      // drop the nearest (the point itself)
       float w = 1.f;
       if (!binary) {
         const float dd = bv * bv;
         w = (flags & SIMAMBA_SPEC_SIGMA_MEAN) ? expf(-dd / inv2s2) : expf(-1.f * alpha * dd);
       }
-      sNb[i * kKnnMaxK + nlist] = bi;
-      sWt[i * kKnnMaxK + nlist] = w;
+      if (part == 0) {
+        sNb[i * kKnnMaxK + nlist] = bi;
+        sWt[i * kKnnMaxK + nlist] = w;
+      }
       ++nlist;
     }
   }
-  // two phases like the reference's two index_put calls: A[i, nn] = w, then A[nn, i] = w
+  __syncthreads();
+  // two phases like the reference's two index_put calls: A[i, nn] = w, then A[nn, i] = w; lane 0 of each quad
   for (int phase = 0; phase < (symmetric ? 2 : 1); ++phase) {
-    for (int q = 0; q < nlist; ++q) {
-      const int bi = sNb[tid * kKnnMaxK + q];
-      const float w = sWt[tid * kKnnMaxK + q];
-      if (phase == 0) sAdj[tid * LD + bi] = w; else sAdj[bi * LD + tid] = w;
+    if (part == 0) {
+      for (int q = 0; q < nlist; ++q) {
+        const int bi = sNb[i * kKnnMaxK + q];
+        const float w = sWt[i * kKnnMaxK + q];
+        if (phase == 0) sAdj[i * LD + bi] = w; else sAdj[bi * LD + i] = w;
+      }
     }
     __syncthreads();
   }
   float* out = adj + static_cast<size_t>(blockIdx.x) * G * G;
-  for (int e = tid; e < G * G; e += kSpecMaxG) {
-    const int i = e / G, j = e - i * G;
-    out[e] = sAdj[i * LD + j];
+  for (int e = tid; e < G * G; e += nthr) {
+    const int r = e / G, c = e - r * G;
+    out[e] = sAdj[r * LD + c];
   }
 }
 
@@ -403,7 +428,7 @@ extern "C" int simamba_knn_graph(const float* points, float* adj, void* workspac
   }
   ensure_lds_attrs();
   const size_t smem = sizeof(float) * (static_cast<size_t>(G) * (G + 1) + G * F + 2 * G * kKnnMaxK);
-  hipLaunchKernelGGL(knn_graph_kernel, dim3(B), dim3(kSpecMaxG), smem, s, points, adj, acc, B, G, F, knn, alpha,
+  hipLaunchKernelGGL(knn_graph_kernel, dim3(B), dim3(G * kKnnLanes), smem, s, points, adj, acc, B, G, F, knn, alpha,
                      flags);
   return static_cast<int>(hipGetLastError());
 }
