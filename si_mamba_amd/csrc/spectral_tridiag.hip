@@ -77,7 +77,7 @@ __global__ __launch_bounds__(kTdThreads) void laplacian_tridiag_kernel(EigArgs p
   extern __shared__ __attribute__((aligned(16))) float S[];     // [G][kTdLD]
   __shared__ float sDeg[kSpecMaxG];
   __shared__ float sV[kSpecMaxG];           // current reflector
-  __shared__ float sW[kSpecMaxG];           // p, then w
+  __shared__ float sW[kSpecMaxG];           // p = tau S22 v
   __shared__ float sTau[kSpecMaxG];
   __shared__ double sD[kSpecMaxG], sE[kSpecMaxG], sE2[kSpecMaxG];
   __shared__ __attribute__((aligned(16))) float sPart[kTdGroups], sPd[kTdGroups];
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(kTdThreads) void laplacian_tridiag_kernel(EigArgs p
   __syncthreads();
 
   // ---- 2. Householder tridiagonalisation ------------------------------------------------------------------
-  // Four barriers per reflector: every lane derives (beta, tau, scale) itself from the group partials of the
+  // Three barriers per reflector: every lane derives (beta, tau, scale) itself from the group partials of the
   // column norm, the p.v product rides on the matvec, and the NEXT column's norm partials ride on the update.
   colnorm_partials(S, LD, G, 0, sPart);
   __syncthreads();
@@ -163,16 +163,17 @@ __global__ __launch_bounds__(kTdThreads) void laplacian_tridiag_kernel(EigArgs p
       }
       if (lane16 == 0) sPd[grp] = pdot;
       __syncthreads();                                                            // (2) p, partial dots
+      // w = p - (tau/2)(p.v) v is formed where it is used (same fmaf everywhere, so every lane sees the same w):
+      // no write-back of w and no barrier for it
       const float alpha = -0.5f * tau * sum_partials(sPd);
-      if (tid < m) sW[tid] = fmaf(alpha, sV[tid], sW[tid]);       // w = p - (tau/2)(p.v) v
-      __syncthreads();                                                            // (3) w
       // S22 -= v w^T + w v^T ; lane 0 of a group also sees the new column k+1 -> next reflector's norm
       float sq = 0.f;
       for (int i = grp; i < m; i += kTdGroups) {
         float* row = S + (k + 1 + i) * LD + (k + 1);
-        const float vi = sV[i], wi = sW[i];
+        const float vi = sV[i], wi = fmaf(alpha, vi, sW[i]);
         for (int j = lane16; j < m; j += 16) {
-          const float nv = row[j] - (vi * sW[j] + wi * sV[j]);
+          const float vj = sV[j], wj = fmaf(alpha, vj, sW[j]);
+          const float nv = row[j] - (vi * wj + wi * vj);
           row[j] = nv;
           if (j == 0 && i >= 1) sq = fmaf(nv, nv, sq);
         }
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(kTdThreads) void laplacian_tridiag_kernel(EigArgs p
     } else {
       colnorm_partials(S, LD, G, k + 1, sPart);
     }
-    __syncthreads();                                                              // (4) trailing block, norms
+    __syncthreads();                                                              // (3) trailing block, norms
   }
   if (tid == 0) {
     if (G >= 2) {
