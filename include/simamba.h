@@ -98,6 +98,8 @@ int simamba_selective_scan_fwd(const void* u, const void* delta, const float* A,
  * nchunks > 1).  du, ddelta, dz : io_dtype (dz NULL iff z NULL).
  * dA (dim,dstate), dB, dC (batch,dstate,seqlen), dD, ddelta_bias (dim): fp32; the library
  * zeroes them on `stream` and then accumulates (float atomics: last-bit run-to-run jitter).
+ * Not one byte outside these five spans is written: spans that are exactly adjacent in memory
+ * (one ends where the next begins) are cleared by a single memset node, all others one by one.
  * dD / ddelta_bias may be NULL when D / delta_bias are NULL.  dB / dC are always contiguous
  * (batch, dstate, seqlen); z, dz and B, C take strides as in the forward.
  */

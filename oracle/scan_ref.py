@@ -151,15 +151,26 @@ class MambaRef(nn.Module):
         self.D._no_weight_decay = True
         self.out_proj = nn.Linear(self.d_inner, d_model, bias=bias)
 
-    def forward(self, hidden_states, inference_params=None):
+    def forward(self, hidden_states, inference_params=None, io_dtype=None):
+        """``io_dtype=torch.bfloat16`` restates the mixer as it runs under ``torch.autocast`` (the reference's
+        pre-training and segmentation runners, tools/runner_pretrain.py:243): upstream ``mamba_inner_fn`` casts
+        the three projection weights (and in_proj goes through autocast's linear) to the autocast dtype, every
+        GEMM, the conv and the scan read and write that dtype and accumulate in fp32, while conv1d.weight/bias,
+        A, D and dt_proj.bias stay fp32.  Here: values are rounded to ``io_dtype`` at exactly those op
+        boundaries and carried as fp32 in between, so a device path with the same roundings differs from this
+        only by accumulation order."""
+        r = (lambda t: t) if io_dtype is None else (lambda t: t.to(io_dtype).float())
         Bsz, L, _ = hidden_states.shape
-        xz = self.in_proj(hidden_states).transpose(1, 2)             # (B,2D,L)
+        xz = F.linear(r(hidden_states), r(self.in_proj.weight), None if self.in_proj.bias is None
+                      else r(self.in_proj.bias))
+        xz = r(xz).transpose(1, 2)                                   # (B,2D,L)
         x, z = xz.chunk(2, dim=1)
-        x = causal_conv1d_ref(x, self.conv1d.weight[:, 0], self.conv1d.bias, "silu")
-        x_dbl = self.x_proj(x.transpose(1, 2))                       # (B,L,R+2N)
+        x = r(causal_conv1d_ref(x, self.conv1d.weight[:, 0], self.conv1d.bias, "silu"))
+        x_dbl = r(F.linear(x.transpose(1, 2), r(self.x_proj.weight)))    # (B,L,R+2N)
         dt, Bm, Cm = torch.split(x_dbl, [self.dt_rank, self.d_state, self.d_state], dim=-1)
-        delta = (dt @ self.dt_proj.weight.t()).transpose(1, 2)       # bias goes into the scan
+        delta = r(dt @ r(self.dt_proj.weight).t()).transpose(1, 2)  # bias goes into the scan
         y = selective_scan_ref(x, delta, -torch.exp(self.A_log.float()),
                                Bm.transpose(1, 2), Cm.transpose(1, 2), self.D.float(),
                                z=z, delta_bias=self.dt_proj.bias.float(), delta_softplus=True)
-        return self.out_proj(y.transpose(1, 2))
+        return r(F.linear(r(y).transpose(1, 2), r(self.out_proj.weight),
+                          None if self.out_proj.bias is None else r(self.out_proj.bias)))

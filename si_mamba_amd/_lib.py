@@ -173,3 +173,22 @@ def scan_workspace(batch, dim, seqlen, dstate, device):
     import torch
     n = load().simamba_scan_fwd_workspace_bytes(batch, dim, seqlen, dstate)
     return torch.empty(n, device=device, dtype=torch.uint8) if n else None
+
+
+def scan_bwd_accumulators(batch, dim, seqlen, dstate, has_D, has_bias, device):
+    """(dA (D,N), dB (B,N,L), dC (B,N,L), dD (D)|None, ddelta_bias (D)|None): the fp32 accumulators
+    simamba_selective_scan_bwd adds into, carved back to back (no padding between them) out of ONE allocation.
+    The library zeroes exactly-adjacent spans with one memset node; it never writes outside the spans it is
+    given, so separately allocated buffers are equally valid, only slower to clear (include/simamba.h)."""
+    import torch
+    sizes = [dim * dstate, batch * dstate * seqlen, batch * dstate * seqlen, dim if has_D else 0,
+             dim if has_bias else 0]
+    flat = torch.empty(sum(sizes), device=device, dtype=torch.float32)
+    parts, o = [], 0
+    for n in sizes:
+        parts.append(flat[o:o + n])
+        o += n
+    dA = parts[0].view(dim, dstate)
+    dB = parts[1].view(batch, dstate, seqlen)
+    dC = parts[2].view(batch, dstate, seqlen)
+    return dA, dB, dC, (parts[3] if has_D else None), (parts[4] if has_bias else None)

@@ -142,7 +142,9 @@ class MixerModel(nn.Module):
             hidden_states, residual = layer(hidden_states, residual, inference_params=inference_params)
             hidden_states = self.drop_out_in_block(hidden_states)
         if hidden_states.is_cuda and type(self.norm_f) is nn.LayerNorm and hidden_states.dim() == 3:
+            # the stack's output norm returns the parameter dtype (fp32) under autocast too, as F.layer_norm does
+            # there; the block norms feed a GEMM and may hand over the autocast dtype directly
             return add_layer_norm_fn(hidden_states, residual, self.norm_f.weight, self.norm_f.bias,
-                                     self.norm_f.eps)[0]
+                                     self.norm_f.eps, out_dtype=self.norm_f.weight.dtype)[0]
         residual = (hidden_states + residual) if residual is not None else hidden_states
         return self.norm_f(residual.to(dtype=self.norm_f.weight.dtype))

@@ -347,8 +347,10 @@ extern "C" int simamba_selective_scan_bwd(const void* u, const void* delta, cons
   if (nchunks > 1 && !x_ckpt) return SIMAMBA_E_NULLPTR;
   hipStream_t s = static_cast<hipStream_t>(stream);
   hipError_t e;
-  // The five accumulators are zeroed here (the kernel adds into them).  When the caller carved them out of one
-  // allocation -- si_mamba_amd/mamba_inner.py does -- that is a single memset node instead of five.
+  // The five accumulators are zeroed here (the kernel adds into them).  Never a byte outside the five spans:
+  // spans that are EXACTLY adjacent in memory (the next one starts where the previous one ends; the Python
+  // callers carve them that way out of one allocation) are merged into one memset node, anything else --
+  // separately allocated buffers, with whatever lives between them -- gets a memset of its own.
   {
     const size_t bc = sizeof(float) * static_cast<size_t>(batch) * dstate * seqlen;
     struct Span { char* p; size_t n; } sp[5] = {{reinterpret_cast<char*>(dA), sizeof(float) * dim * dstate},
@@ -357,20 +359,16 @@ extern "C" int simamba_selective_scan_bwd(const void* u, const void* delta, cons
                                                  {reinterpret_cast<char*>(dD), dD ? sizeof(float) * dim : 0},
                                                  {reinterpret_cast<char*>(ddelta_bias),
                                                   ddelta_bias ? sizeof(float) * dim : 0}};
-    char* lo = nullptr;
-    char* hi = nullptr;
-    size_t total = 0;
-    for (const Span& x : sp) {
-      if (!x.n) continue;
-      lo = (!lo || x.p < lo) ? x.p : lo;
-      hi = (!hi || x.p + x.n > hi) ? x.p + x.n : hi;
-      total += x.n;
-    }
-    if (total && static_cast<size_t>(hi - lo) <= total + 5 * 256) {        // contiguous up to alignment padding
+    for (int i = 1; i < 5; ++i)                      // insertion sort by address
+      for (int j = i; j > 0 && sp[j].p < sp[j - 1].p; --j) { const Span t = sp[j]; sp[j] = sp[j - 1]; sp[j - 1] = t; }
+    for (int i = 0; i < 5;) {
+      if (!sp[i].n) { ++i; continue; }
+      char* lo = sp[i].p;
+      char* hi = lo + sp[i].n;
+      int j = i + 1;
+      while (j < 5 && (sp[j].n == 0 || sp[j].p == hi)) { hi += sp[j].n; ++j; }
       if ((e = hipMemsetAsync(lo, 0, static_cast<size_t>(hi - lo), s)) != hipSuccess) return static_cast<int>(e);
-    } else {
-      for (const Span& x : sp)
-        if (x.n && (e = hipMemsetAsync(x.p, 0, x.n, s)) != hipSuccess) return static_cast<int>(e);
+      i = j;
     }
   }
   if (batch == 0 || seqlen == 0) return SIMAMBA_OK;

@@ -101,7 +101,17 @@ class BnReluFn(torch.autograd.Function):
 
 
 def bn_relu_fn(x, bn: torch.nn.BatchNorm1d, gterm=None, group=0):
-    """relu(bn(x + gterm[row // group])) for token-major x (rows, C) with ``bn``'s parameters, buffers and mode."""
+    """relu(bn(x + gterm[row // group])) for token-major x (rows, C) with ``bn``'s parameters, buffers and mode.
+
+    The HIP kernel computes PER-RANK batch statistics, which is what ``nn.BatchNorm1d`` means.  Any other module
+    type -- in particular the ``nn.SyncBatchNorm`` that ``--sync_bn`` puts in its place
+    (reference tools/runner_finetune.py:121-122, runner_pretrain.py:111-112), whose training statistics are reduced
+    across ranks -- goes through the module itself (stock torch kernels on the same device), so its semantics are
+    kept instead of being silently replaced."""
+    if type(bn) is not torch.nn.BatchNorm1d:
+        if gterm is not None:
+            x = x + gterm.to(x.dtype).repeat_interleave(group, dim=0)
+        return torch.relu(bn(x))
     training = bn.training or bn.running_mean is None
     momentum = bn.momentum
     if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:

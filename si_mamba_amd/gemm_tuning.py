@@ -25,7 +25,11 @@ def enable_tuned_gemms(path: str | None = None) -> bool:
     tunable.enable(True)
     tunable.tuning_enable(False)          # look-up only
     tunable.record_untuned_enable(False)
-    # TunableOp writes its table back to `filename` at exit: point that at a scratch copy name so the shipped
-    # file is never modified, then load the shipped table
-    tunable.set_filename(os.path.join(os.environ.get("TMPDIR", "/tmp"), f"simamba_tunableop_{os.getpid()}.csv"))
+    # Look-up only.  TunableOp rewrites its table to `filename` when the process ends: switch that off where the
+    # PyTorch build has the switch (torch.cuda.tunable.write_file_on_exit); otherwise aim it at ONE fixed scratch
+    # name, so the shipped file is never touched and runs do not leave a file per process behind.
+    if hasattr(tunable, "write_file_on_exit"):
+        tunable.write_file_on_exit(False)
+    else:
+        tunable.set_filename(os.path.join(os.environ.get("TMPDIR", "/tmp"), "simamba_tunableop_scratch.csv"))
     return bool(tunable.read_file(path))

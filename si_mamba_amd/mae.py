@@ -252,7 +252,24 @@ class Point_MAE_Mamba(nn.Module):
                                                  self.binary)
         return spectral._eig(adj, self.k_top_eigenvectors, self.smallest, False, want_all=False, want_order=True)[4]
 
-    def forward(self, pts, noaug=False, orders=None, mask=None, return_parts=False, **kwargs):
+    def forward(self, pts, noaug=False, vis=False, tau=None, use_wavelets=False, use_diff_sort=False,
+                ret_policy=False, ret_only_policy=False, save_pts_dir=None, epoch=None, orders=None, mask=None,
+                return_parts=False, **kwargs):
+        """Reference signature (models/point_mamba.py:3053-3054; the pre-training runner calls
+        ``base_model(points, tau=tau, ret_policy=False, use_wavelets=True)``, tools/runner_pretrain.py:244).
+        Built: the spectral-order route of the published method.  The wavelet-traversal, learned-permutation,
+        differentiable-sort, policy and visualisation branches are outside the hot-path scope (SURVEY.md section
+        2) and are refused by name instead of being silently replaced by the spectral orders.  ``orders`` / ``mask``
+        / ``return_parts`` are this package's test hooks; ``save_pts_dir`` / ``epoch`` only feed the reference's
+        point dumps and are ignored."""
+        for name, on in (("tau", tau is not None), ("use_wavelets", use_wavelets), ("use_diff_sort", use_diff_sort),
+                         ("ret_policy", ret_policy), ("ret_only_policy", ret_only_policy), ("vis", vis)):
+            if on:
+                raise NotImplementedError(f"Point_MAE_Mamba.forward({name}=...): that branch of reference "
+                                          "models/point_mamba.py:3053-3219 is outside the SI-Mamba hot-path scope; "
+                                          "the spectral-order route runs with the argument left at its default")
+        if kwargs:
+            raise TypeError(f"Point_MAE_Mamba.forward: unexpected arguments {sorted(kwargs)}")
         neighborhood, center, _ = self.group_divider(pts)
         B, G, M, _ = neighborhood.shape
         if orders is None:

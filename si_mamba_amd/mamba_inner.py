@@ -169,19 +169,9 @@ class MambaInnerFn(torch.autograd.Function):
         dxz = torch.empty_like(xz)
         du = torch.empty(Bsz, Dm, L, device=dev, dtype=io)
         ddelta = torch.empty(Bsz, Dm, L, device=dev, dtype=io)
-        # the five fp32 accumulators of the scan backward share one allocation: the library zeroes them with a
-        # single memset when they are contiguous (64-float aligned pieces)
-        sizes = [Dm * N, Bsz * N * L, Bsz * N * L, Dm if Df is not None else 0, Dm if bf is not None else 0]
-        offs, tot = [], 0
-        for n in sizes:
-            offs.append(tot)
-            tot += (n + 63) // 64 * 64
-        flat = torch.empty(tot, **f32)
-        dA = flat[offs[0]:offs[0] + sizes[0]].view(Dm, N)
-        dB = flat[offs[1]:offs[1] + sizes[1]].view(Bsz, N, L)
-        dC = flat[offs[2]:offs[2] + sizes[2]].view(Bsz, N, L)
-        dD = flat[offs[3]:offs[3] + sizes[3]] if Df is not None else None
-        dbias = flat[offs[4]:offs[4] + sizes[4]] if bf is not None else None
+        # the five fp32 accumulators of the scan backward are carved back to back out of one allocation: the
+        # library zeroes exactly-adjacent spans with a single memset node
+        dA, dB, dC, dD, dbias = _lib.scan_bwd_accumulators(Bsz, Dm, L, N, Df is not None, bf is not None, dev)
         Bv, Cv = x_dbl[:, :, R:R + N], x_dbl[:, :, R + N:]
         z, dz = xz[:, Dm:], dxz[:, Dm:]
         with torch.cuda.device(dev), _lib.timed("scan_bwd", dev):

@@ -109,6 +109,11 @@ def default_config(**over):
     return SimpleNamespace(**cfg)
 
 
+def plackett_luce_dist(logits):
+    """log-probability of the identity permutation under a Plackett-Luce model (reference :2131-2132)."""
+    return torch.sum(logits - torch.logcumsumexp(logits.flip(-1), dim=-1).flip(-1), dim=-1)
+
+
 class PointMamba(nn.Module):
     def __init__(self, config, **kwargs):
         super().__init__()
@@ -162,10 +167,14 @@ class PointMamba(nn.Module):
         acc = (pred == gt).sum() / float(gt.size(0))
         return loss, acc * 100
 
-    def spectral_order(self, center):
+    def spectral_eigs(self, center):
+        """(vals (B,k), vecs (B,G,k), order (B,k,G)) of the fused graph + eigen + argsort kernels."""
         return spectral.spectral_order(center, self.knn_graph, self.alpha, self.k_top_eigenvectors,
                                        smallest=self.smallest, symmetric=self.symmetric,
-                                       self_loop=self.self_loop, binary=self.binary, matrix=self.matrix)[2]
+                                       self_loop=self.self_loop, binary=self.binary, matrix=self.matrix)
+
+    def spectral_order(self, center):
+        return self.spectral_eigs(center)[2]
 
     def order_tokens(self, tokens, pos, center, order=None):
         """Tokens and positions in sequence order for ``self.method`` (reference :850-1112)."""
@@ -185,9 +194,27 @@ class PointMamba(nn.Module):
         t, p, _, _ = spectral.hlt_assemble(tokens, pos, center, vecs, self.k_top_eigenvectors, rand=rand)
         return t, p
 
-    def forward(self, pts, gt=None):
+    def forward(self, pts, gt=None, tau=None, use_wavelets=False, save_pts_dir=None, epoch=None):
+        """Reference signature (models/point_mamba.py:843; the runner calls
+        ``base_model(points, gt=None, tau=None, use_wavelets=True)``, tools/runner_finetune.py:201).  Built: the
+        published spectral route (``tau is None``, ``use_wavelets=False``).  ``gt`` given -> ``(logits, policy)``
+        with the reference's Plackett-Luce log-probability of the eigen-ordering (:953-955).  The learned-permutation
+        (``tau``) and wavelet-traversal (``use_wavelets``) research branches are outside the hot-path scope
+        (the wavelet branch calls a function the reference never defines, :879) and are
+        refused by name rather than silently replaced.  ``save_pts_dir`` / ``epoch`` only feed the reference's
+        point-dump visualisation and are ignored."""
+        if tau is not None:
+            raise NotImplementedError("PointMamba.forward(tau=...): the learned-permutation branch (reference "
+                                      "models/point_mamba.py:902-952) is outside the SI-Mamba hot-path scope")
+        if use_wavelets:
+            raise NotImplementedError("PointMamba.forward(use_wavelets=True): the wavelet-traversal orders (reference "
+                                      "models/point_mamba.py:874-880, 957-980) are outside the SI-Mamba hot-path scope; "
+                                      "call with use_wavelets=False for the spectral ordering")
+        want_policy = gt is not None
+        if want_policy and self.method != "SAST":
+            raise NotImplementedError("PointMamba.forward(gt=...): the reference defines `policy` on the SAST route only")
         neighborhood, center, _ = self.group_divider(pts)
-        order = None
+        order = spec = None
         overlap = center.is_cuda and self.method == "SAST"
         # The eigen-ordering depends only on the centres and is latency-bound on B of the 256 CUs: run it
         # on a side HIP stream underneath the (MFMA-bound) patch encoder, join before the gather.
@@ -196,15 +223,24 @@ class PointMamba(nn.Module):
             side = self._side_stream(center.device)
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                order = self.spectral_order(center)
+                spec = self.spectral_eigs(center)
+                order = spec[2]
             center.record_stream(side)
         tokens = self.encoder(neighborhood)
         pos = self.pos_embed(center)
         if overlap:
             main.wait_stream(side)
-            order.record_stream(main)
+            for t in spec:
+                t.record_stream(main)
         x, pos = self.order_tokens(tokens, pos, center, order)
         x = self.drop_out(x)
         x = self.blocks(x, pos)
         x = self.norm(x)
-        return self.cls_head_finetune(x.mean(1))
+        ret = self.cls_head_finetune(x.mean(1))
+        if not want_policy:
+            return ret
+        if spec is None:
+            spec = self.spectral_eigs(center)
+        vals, vecs, _ = spec
+        ordered_vecs = torch.sort(vecs.transpose(1, 2), dim=-1)[0]                 # :954
+        return ret, plackett_luce_dist(-ordered_vecs).sum(-1) + plackett_luce_dist(vals)

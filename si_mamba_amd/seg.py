@@ -73,7 +73,7 @@ class MixerModelForSegmentation(nn.Module):
             if i in self.fetch_idx:
                 if hidden_states.is_cuda:
                     feats.append(add_layer_norm_fn(hidden_states, residual, self.norm_f.weight, self.norm_f.bias,
-                                                   self.norm_f.eps)[0])
+                                                   self.norm_f.eps, out_dtype=self.norm_f.weight.dtype)[0])
                 else:
                     feats.append(self.norm_f((hidden_states + residual).to(self.norm_f.weight.dtype)))
         return feats

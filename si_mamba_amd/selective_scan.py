@@ -94,12 +94,8 @@ class SelectiveScanFn(torch.autograd.Function):
         du = torch.empty_like(uc)
         ddelta = torch.empty_like(uc)
         dz = torch.empty_like(uc) if zc is not None else None
-        f32 = dict(device=uc.device, dtype=torch.float32)
-        dA = torch.empty(dim, N, **f32)
-        dB = torch.empty(batch, N, L, **f32)
-        dC = torch.empty(batch, N, L, **f32)
-        dD = torch.empty(dim, **f32) if Dc is not None else None
-        dbias = torch.empty(dim, **f32) if bc is not None else None
+        dA, dB, dC, dD, dbias = _lib.scan_bwd_accumulators(batch, dim, L, N, Dc is not None, bc is not None,
+                                                           uc.device)
         with torch.cuda.device(uc.device), _lib.timed("scan_bwd", uc.device):
             rc = lib.simamba_selective_scan_bwd(
                 _lib.ptr(uc), _lib.ptr(dc), _lib.ptr(Ac), _lib.ptr(Bc), _lib.ptr(Cc), _lib.ptr(Dc),

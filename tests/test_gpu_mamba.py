@@ -50,17 +50,34 @@ def test_block_and_stack_match_reference_semantics(device):
     assert torch.equal(r0.cpu(), x)
 
 
-def test_mamba_bf16_autocast(device):
+@pytest.mark.parametrize("shape", [(2, 50, 64), (2, 1024, 384), (4, 208, 384)])
+def test_mamba_bf16_autocast(shape, device):
+    """The mixer under bf16 autocast (tools/runner_pretrain.py:243) against the oracle restated with the autocast
+    roundings (MambaRef.forward io_dtype: every GEMM, the conv and the scan read and write bf16, accumulate fp32;
+    conv weights, A, D, dt bias fp32).  north_star tolerance for bf16: 1e-2 on the normalised error -- forward and
+    the gradients of the input and of every parameter (the oracle's backward carries fp32 gradients between the ops
+    where the device carries bf16 ones: that difference is inside the same budget)."""
     from si_mamba_amd import Mamba
+    B, L, d = shape
     torch.manual_seed(1)
-    m = Mamba(64).to(device)
-    ref = scan_ref.MambaRef(64)
+    m = Mamba(d).to(device)
+    ref = scan_ref.MambaRef(d)
     ref.load_state_dict({k: v.cpu() for k, v in m.state_dict().items()})
-    h = torch.randn(2, 50, 64)
+    h = torch.randn(B, L, d)
+    dout = torch.randn(B, L, d)
+    hd = h.to(device).requires_grad_(True)
     with torch.autocast("cuda", dtype=torch.bfloat16):
-        got = m(h.to(device))
+        got = m(hd)
     assert got.dtype == torch.bfloat16
-    assert nerr(got.float(), ref(h)) < 3e-2     # bf16 GEMMs + bf16 scan I/O vs fp32 oracle
+    got.backward(dout.to(device).to(got.dtype))
+    hr = h.clone().requires_grad_(True)
+    want = ref(hr, io_dtype=torch.bfloat16)
+    want.backward(dout.to(torch.bfloat16).float())
+    assert nerr(got.float(), want) < 1e-2
+    assert nerr(hd.grad, hr.grad) < 1e-2
+    pg = dict(m.named_parameters())
+    for k, p in ref.named_parameters():
+        assert nerr(pg[k].grad, p.grad) < 1e-2, k
 
 
 def test_inference_params_refused(device):
@@ -89,7 +106,7 @@ def test_fused_inner_fn_equals_composed_ops(shape, dtype, device):
             o = m(hd)
         o.backward(dout.to(device).to(o.dtype))
         outs.append((o.float(), hd.grad, {k: p.grad for k, p in m.named_parameters()}))
-    tol = 1e-3 if dtype == torch.float32 else 3e-2
+    tol = 1e-3 if dtype == torch.float32 else 1e-2
     assert nerr(outs[0][0], outs[1][0]) < tol
     assert nerr(outs[0][1], outs[1][1]) < tol
     for k in outs[0][2]:

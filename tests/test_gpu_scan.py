@@ -129,9 +129,18 @@ def test_scan_empty_inputs(device):
 
 
 # ---- BASELINE-size checks through size-independent properties -------------------------------------
+_full_cache = {}
+
+
 def _full(device, b, d, L, seed):
-    inp = scan_inputs(b, d, L, 16, seed=seed)
-    return {k: (v.to(device) if v is not None else None) for k, v in inp.items()}
+    """Full-size synthetic inputs on the device (generated once per shape and seed: the seeded CPU generator takes
+    tens of seconds at these sizes)."""
+    key = (b, d, L, seed)
+    if key not in _full_cache:
+        _full_cache.clear()                     # one shape resident at a time (1.2 GB at the model shape)
+        inp = scan_inputs(b, d, L, 16, seed=seed)
+        _full_cache[key] = {k: (v.to(device) if v is not None else None) for k, v in inp.items()}
+    return dict(_full_cache[key])
 
 
 @pytest.mark.parametrize("shape", [(256, 768, 128), (64, 768, 1024)])
@@ -163,24 +172,71 @@ def test_scan_full_size_properties(shape, device):
     assert torch.equal(out_p, out[perm])
 
 
-def test_scan_backward_full_size_against_row_subset(device):
-    """Backward at the headline shape: du/ddelta/dz rows vs the oracle on a row subset (those gradients are
-    per-row), and dA/dD/dbias/dB/dC as sums checked on a reduced-batch replay of the same rows."""
+def _oracle_grads(t, bsel, dsel, dtype, threads=None):
+    """Oracle forward + backward restricted to samples ``bsel`` and channels ``dsel`` (index tensors / slices) of the
+    device tensors ``t``; activations rounded to ``dtype`` like the kernel's inputs, fp32 accumulation.
+    ``threads``: CPU threads for the step loop (its per-step tensors are tiny for a channel subset: one thread is
+    ~20x faster there than a thread pool that synchronises 10 times per step)."""
+    if threads is not None:
+        keep = torch.get_num_threads()
+        torch.set_num_threads(threads)
+        try:
+            return _oracle_grads(t, bsel, dsel, dtype)
+        finally:
+            torch.set_num_threads(keep)
+    act = lambda x: x.to(dtype).float().cpu()
+    leaf = {
+        "u": act(t["u"][bsel][:, dsel]), "delta": act(t["delta"][bsel][:, dsel]), "z": act(t["z"][bsel][:, dsel]),
+        "B": act(t["B"][bsel]), "C": act(t["C"][bsel]),
+        "A": t["A"][dsel].cpu().clone(), "D": t["D"][dsel].cpu().clone(), "delta_bias": t["delta_bias"][dsel].cpu().clone(),
+    }
+    for v in leaf.values():
+        v.requires_grad_(True)
+    out = scan_ref.selective_scan_ref(leaf["u"], leaf["delta"], leaf["A"], leaf["B"], leaf["C"], leaf["D"], leaf["z"],
+                                      leaf["delta_bias"], True)
+    out.backward(act(t["dout"][bsel][:, dsel]))
+    return {k: v.grad for k, v in leaf.items()}
+
+
+@pytest.mark.parametrize("shape,dtype", [((64, 768, 1024), torch.float32), ((64, 768, 1024), torch.bfloat16),
+                                          ((128, 768, 256), torch.float32)])
+def test_scan_backward_full_size_reductions(shape, dtype, device):
+    """Backward at the model shape (64,768,1024,16) -- what every Mamba block of the bench step runs: several channel
+    passes per workgroup, 8 chunks with carried adjoint states, the cross-wave LDS sum and the float-atomic dB / dC
+    flush from >= 512 workgroups with the XCD relabelling -- and at two shapes with other pass / chunk counts.
+      * du / ddelta / dz (per element): rows of a few samples x channels against the oracle on exactly those rows;
+      * dA / dD / ddelta_bias (sums over batch and time): a channel subset against the oracle run on ALL samples of
+        those channels;
+      * dB / dC (sums over channels): two samples against the oracle run on ALL 768 channels of those samples."""
     from si_mamba_amd import selective_scan_fn
-    b, d, L = 64, 768, 128
+    b, d, L = shape
     t = _full(device, b, d, L, seed=2)
-    leaves = {k: t[k].clone().requires_grad_(True) for k in ("u", "delta", "z")}
-    out = selective_scan_fn(leaves["u"], leaves["delta"], t["A"], t["B"], t["C"], t["D"], leaves["z"],
-                            t["delta_bias"], True)
-    out.backward(t["dout"])
-    bi, ds = 5, torch.arange(0, d, 37)
-    sub = {k: t[k][bi:bi + 1, ds].cpu().clone().requires_grad_(True) for k in ("u", "delta", "z")}
-    want = scan_ref.selective_scan_ref(sub["u"], sub["delta"], t["A"][ds].cpu(), t["B"][bi:bi + 1].cpu(),
-                                       t["C"][bi:bi + 1].cpu(), t["D"][ds].cpu(), sub["z"],
-                                       t["delta_bias"][ds].cpu(), True)
-    want.backward(t["dout"][bi:bi + 1, ds].cpu())
+    act = ("u", "delta", "z", "B", "C", "dout")
+    tt = {k: (v.to(dtype) if k in act else v) for k, v in t.items()}
+    leaves = {k: tt[k].clone().requires_grad_(True) for k in ("u", "delta", "z", "B", "C", "A", "D", "delta_bias")}
+    out = selective_scan_fn(leaves["u"], leaves["delta"], leaves["A"], leaves["B"], leaves["C"], leaves["D"],
+                            leaves["z"], leaves["delta_bias"], True)
+    out.backward(tt["dout"])
+    tol = TOL[dtype]
+    got = {k: v.grad for k, v in leaves.items()}
+    # (i) parameter gradients of a channel subset, summed over every sample and step
+    ds = torch.tensor([0, 5, 17, 255, 256, 400, 766, 767], device=device)
+    want = _oracle_grads(tt, slice(None), ds, dtype, threads=1)
+    for k, name in (("A", "dA"), ("D", "dD"), ("delta_bias", "ddelta_bias")):
+        assert nerr(got[k][ds], want[k]) < tol, name
     for k in ("u", "delta", "z"):
-        assert nerr(leaves[k].grad[bi:bi + 1, ds], sub[k].grad) < 1e-3, k
+        assert nerr(got[k][:, ds], want[k]) < tol, k
+    # (ii) dB / dC of two samples, summed over all channels
+    bs = torch.tensor([3, b - 1], device=device)
+    want = _oracle_grads(tt, bs, slice(None), dtype)
+    for k in ("B", "C"):
+        assert nerr(got[k][bs], want[k]) < tol, "d" + k
+    for k in ("u", "delta", "z"):
+        assert nerr(got[k][bs], want[k]) < tol, k
+    # the remaining samples' dB / dC: finite, and no sample was skipped or flushed twice -- a sample's dC norm is
+    # of the order of the checked ones
+    nrm = got["C"].float().flatten(1).norm(dim=1)
+    assert torch.isfinite(nrm).all() and (nrm > 0.25 * nrm[bs].min()).all() and (nrm < 4 * nrm[bs].max()).all()
 
 
 # ---- the one-lane-per-channel forward (taken when batch*dim >= 98304 and rows are pack-aligned) ----------
@@ -240,3 +296,63 @@ def test_scan_strided_operands(device):
     assert torch.equal(a, b)
     a.backward(t["dout"]); b.backward(t["dout"])
     torch.testing.assert_close(u.grad, u2.grad, rtol=1e-5, atol=1e-5)
+
+
+def test_scan_backward_writes_nothing_outside_its_accumulators(device):
+    """The five fp32 accumulators handed over as SEPARATE allocations with sentinel tensors between them (the
+    caching allocator packs small blocks back to back): the library's zero-fill must leave every sentinel intact,
+    and the gradients must equal those of the carved-from-one-allocation call."""
+    from si_mamba_amd import _lib
+    lib = _lib.load()
+    b, d, L, N = 2, 24, 40, 16
+    inp = scan_inputs(b, d, L, N, seed=31)
+    t = {k: v.to(device) for k, v in inp.items()}
+    out = torch.empty_like(t["u"])
+    st = _lib.stream_ptr(device)
+    rc = lib.simamba_selective_scan_fwd(_lib.ptr(t["u"]), _lib.ptr(t["delta"]), _lib.ptr(t["A"]), _lib.ptr(t["B"]),
+                                        _lib.ptr(t["C"]), _lib.ptr(t["D"]), _lib.ptr(t["z"]),
+                                        _lib.ptr(t["delta_bias"]), _lib.ptr(out), None, None, b, d, L, N, 0, 1,
+                                        0, 0, 0, 0, None, 0, st)
+    assert rc == 0
+
+    def bwd(acc):
+        du, dd, dz = (torch.empty_like(t["u"]) for _ in range(3))
+        rc = lib.simamba_selective_scan_bwd(
+            _lib.ptr(t["u"]), _lib.ptr(t["delta"]), _lib.ptr(t["A"]), _lib.ptr(t["B"]), _lib.ptr(t["C"]),
+            _lib.ptr(t["D"]), _lib.ptr(t["z"]), _lib.ptr(t["delta_bias"]), _lib.ptr(t["dout"]), None,
+            _lib.ptr(du), _lib.ptr(dd), *[_lib.ptr(a) for a in acc[:4]], _lib.ptr(dz), _lib.ptr(acc[4]),
+            b, d, L, N, 0, 1, 0, 0, 0, 0, 0, st)
+        assert rc == 0
+        return du, dd, dz
+
+    # (a) one slab, accumulators separated by 64-float sentinels, filled with garbage first
+    sizes = [d * N, b * N * L, b * N * L, d, d]
+    slab = torch.full((sum(sizes) + 64 * 6,), 7.0, device=device)
+    acc, sent, o = [], [], 0
+    for n in sizes:
+        sent.append(slab[o:o + 64]); o += 64
+        acc.append(slab[o:o + n]); o += n
+    sent.append(slab[o:o + 64])
+    g_a = bwd(acc)
+    torch.cuda.synchronize()
+    for s in sent:
+        assert (s == 7.0).all()
+    # (b) separately allocated small tensors with foreign live blocks in between
+    acc_b, keep = [], []
+    for n in sizes:
+        acc_b.append(torch.full((n,), 3.0, device=device))
+        keep.append(torch.full((32,), 5.0, device=device))
+    g_b = bwd(acc_b)
+    # (c) the product's carve
+    acc_c = _lib.scan_bwd_accumulators(b, d, L, N, True, True, device)
+    for a in acc_c:
+        a.fill_(9.0)
+    g_c = bwd([a.view(-1) for a in acc_c])
+    torch.cuda.synchronize()
+    for k in keep:
+        assert (k == 5.0).all()
+    for x, y, z in zip(acc, acc_b, acc_c):
+        torch.testing.assert_close(x, y, rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(x, z.view(-1), rtol=1e-5, atol=1e-5)
+    for x, y in zip(g_a, g_b):
+        assert torch.equal(x, y)

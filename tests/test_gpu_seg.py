@@ -107,3 +107,36 @@ def test_partseg_train_step_reference_sizes(device):
     assert torch.isfinite(loss)
     missing = [k for k, p in m.named_parameters() if p.grad is None or not torch.isfinite(p.grad).all()]
     assert not missing, missing
+
+
+@pytest.mark.parametrize("method,npts", [("HLT", 2048), ("SAST", 2048)])
+def test_partseg_full_depth_bf16_matches_oracle(method, npts, device):
+    """BASELINE config 5: the ShapeNetPart architecture (12 blocks, d = 384, taps after layers 3 / 7 / 11, 128 patches
+    of 32; HLT -> L = 256, SAST -> L = 1024) on 2048 points under bf16 autocast, against the oracle restated with the
+    autocast roundings (tests/compose.py, oracle/seg_ref.py).  1e-2 on the normalised error of the per-point
+    log-probabilities (north_star's bf16 tolerance)."""
+    from compose import nerr as nerr1, oracle_stack
+    from si_mamba_amd.seg import PartSegMamba, default_seg_config
+    torch.manual_seed(0)
+    cfg = default_seg_config(drop_path=0., drop_path_rate=0., method=method)
+    m = PartSegMamba(50, cfg).to(device).eval()
+    m.hlt_rand = False
+    B, N = 2, npts
+    pts = _clouds(B, N, 3).transpose(1, 2).contiguous()                 # (B, 3, N)
+    label = torch.zeros(B, 16); label[0, 3] = 1; label[1, 7] = 1
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        got = m(pts.to(device), label.to(device)).float().cpu()
+        nb, center, _ = m.group_divider(pts.transpose(1, 2).contiguous().to(device))
+        x, spos, scenter = m.order_tokens(m.encoder(nb), m.pos_embed(center), center)
+        x, spos, scenter = x.cpu(), spos.cpu(), scenter.cpu()
+    assert x.shape == (B, 256 if method == "HLT" else 1024, 384)
+    cpu = m.cpu()
+    with torch.no_grad():
+        feats = oracle_stack(cpu.blocks, 384, torch.bfloat16, taps=cpu.blocks.fetch_idx)(x, spos)
+        want = seg_ref.seg_head(cpu, pts, label, scenter.float(), feats, io_dtype=torch.bfloat16)
+    assert got.shape == (B, N, 50)
+    assert nerr1(got, want) < 1e-2
+    # and the class decisions agree wherever the oracle's top-2 margin is not a near-tie
+    top2 = want.topk(2, dim=-1)[0]
+    clear = (top2[..., 0] - top2[..., 1]) > 0.1
+    assert (got.argmax(-1) == want.argmax(-1))[clear].all()
