@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define SIMAMBA_ABI_VERSION 5
+#define SIMAMBA_ABI_VERSION 6
 
 #define SIMAMBA_F32  0
 #define SIMAMBA_BF16 1
@@ -59,6 +59,7 @@ extern "C" {
 #define SIMAMBA_E_WORKSPACE  -6
 #define SIMAMBA_E_GROUPS     -7   /* G in [2,128], knn + 1 <= min(G,32), k (+1) <= G, F in [1,64] */
 #define SIMAMBA_E_ALIGN      -8
+#define SIMAMBA_E_VARIANT    -9   /* unknown forward-scan variant, or one the shape / alignment cannot take */
 
 /* timesteps per scan chunk; simamba_scan_num_chunks(L) = ceil(L / chunk) */
 #define SIMAMBA_SCAN_CHUNK 128
@@ -78,20 +79,24 @@ int         simamba_scan_num_chunks(int seqlen);
  *   x_ckpt           : (batch, dim, nchunks, dstate) fp32 or NULL.  State at the END of every
  *                      chunk; required by the backward when nchunks > 1.
  *   last_state       : (batch, dim, dstate) fp32 or NULL.
- *   workspace        : optional scratch of >= simamba_scan_fwd_workspace_bytes(...) bytes.  When given
- *                      and that function returned non-zero, the "one lane per channel" kernel runs
- *                      (B_t, C_t packed to (batch, seqlen, 32) fp32 in the workspace and read through
- *                      scalar loads); otherwise the row-scan kernel, which needs no scratch.
+ *   variant          : SIMAMBA_SCAN_AUTO in production: the library picks the kernel from the shape (no
+ *                      environment variables, no global state).  The explicit values select one kernel for
+ *                      benchmarks and parity tests: ROWSCAN (16 lanes per row, any shape), LPC2 / LPC4 (2 / 4
+ *                      lanes per channel, 32-step chunks; need dstate == 16, 16-byte aligned rows and tensors
+ *                      below 2^30 elements, else SIMAMBA_E_VARIANT).  All variants compute the same function.
  *   out = (scan(u, softplus?(delta + delta_bias), A, B, C) + D*u) * silu(z)
  */
-size_t simamba_scan_fwd_workspace_bytes(int batch, int dim, int seqlen, int dstate);
+#define SIMAMBA_SCAN_AUTO    0
+#define SIMAMBA_SCAN_ROWSCAN 1
+#define SIMAMBA_SCAN_LPC2    2
+#define SIMAMBA_SCAN_LPC4    4
 int simamba_selective_scan_fwd(const void* u, const void* delta, const float* A,
                                const void* B, const void* C, const float* D, const void* z,
                                const float* delta_bias, void* out, float* x_ckpt,
                                float* last_state, int batch, int dim, int seqlen, int dstate,
                                int io_dtype, int delta_softplus, long long z_bstride,
                                long long bc_bstride, long long bc_nstride, long long bc_tstride,
-                               void* workspace, size_t ws_bytes, void* stream);
+                               int variant, void* stream);
 
 /*
  * Selective scan backward.  Inputs as forward (+ dout, x_ckpt from the forward when

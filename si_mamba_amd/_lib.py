@@ -22,18 +22,20 @@ SPEC_MATRIX_SYM = 0x08
 SPEC_SMALLEST = 0x10
 SPEC_SIGMA_MEAN = 0x20
 
+# forward-scan kernel selection (include/simamba.h): AUTO in production, the others for benchmarks / parity tests
+SCAN_AUTO, SCAN_ROWSCAN, SCAN_LPC2, SCAN_LPC4 = 0, 1, 2, 4
+
 # name -> (restype, argtypes); mirrors include/simamba.h one to one
 _P = c_void_p
 _LL = c_longlong
-ABI_VERSION = 5
+ABI_VERSION = 6
 SIGNATURES = {
     "simamba_abi_version": (c_int, []),
     "simamba_strerror": (c_char_p, [c_int]),
     "simamba_scan_num_chunks": (c_int, [c_int]),
     "simamba_selective_scan_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                            c_int, c_int, c_int, c_int, c_int, c_int,
-                                           _LL, _LL, _LL, _LL, _P, c_size_t, _P]),
-    "simamba_scan_fwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+                                           _LL, _LL, _LL, _LL, c_int, _P]),
     "simamba_selective_scan_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                            _P, _P, _P, _P, _P, _P, _P, _P,
                                            c_int, c_int, c_int, c_int, c_int, c_int,
@@ -166,13 +168,28 @@ def kernel_times():
     return out
 
 
-def scan_workspace(batch, dim, seqlen, dstate, device):
-    """Scratch the forward entry point asks for (simamba_scan_fwd_workspace_bytes): none since ABI 3's
-    lane-per-channel kernel reads B / C in place, so this returns None; kept so callers stay written
-    against the ABI's workspace contract."""
-    import torch
-    n = load().simamba_scan_fwd_workspace_bytes(batch, dim, seqlen, dstate)
-    return torch.empty(n, device=device, dtype=torch.uint8) if n else None
+_scan_variant = [SCAN_AUTO]
+
+
+class scan_variant:
+    """Context manager for benchmarks and parity tests: the forward-scan kernel the Python ops request from the
+    library inside the block (an explicit argument of simamba_selective_scan_fwd -- the library itself holds no
+    state and reads no environment).  Production code never enters it: SCAN_AUTO lets the library choose."""
+
+    def __init__(self, variant):
+        self.v, self.prev = int(variant), None
+
+    def __enter__(self):
+        self.prev, _scan_variant[0] = _scan_variant[0], self.v
+        return self
+
+    def __exit__(self, *exc):
+        _scan_variant[0] = self.prev
+        return False
+
+
+def current_scan_variant():
+    return _scan_variant[0]
 
 
 def scan_bwd_accumulators(batch, dim, seqlen, dstate, has_D, has_bias, device):

@@ -16,6 +16,7 @@ extern "C" const char* simamba_strerror(int rc) {
     case SIMAMBA_E_WORKSPACE: return "simamba: workspace missing or too small";
     case SIMAMBA_E_GROUPS: return "simamba: need 2 <= G <= 128, knn + 1 <= min(G, 32), k (+1) <= G, 1 <= F <= 64";
     case SIMAMBA_E_ALIGN: return "simamba: pointer not aligned";
+    case SIMAMBA_E_VARIANT: return "simamba: scan variant unknown or not applicable to this shape";
     default: break;
   }
   if (rc > 0) return hipGetErrorString(static_cast<hipError_t>(rc));

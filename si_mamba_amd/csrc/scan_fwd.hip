@@ -160,26 +160,22 @@ static int launch_fwd(const ScanArgs& a, hipStream_t s) {
 
 int scan_fwd_seq_dispatch(const void* u, const void* delta, const float* A, const void* B, const void* C, const float* D,
                           const void* z, const float* delta_bias, void* out, float* x_ckpt, float* last_state,
-                          int batch, int dim, int seqlen, int io_dtype, int delta_softplus, long long z_bs,
-                          long long bc_bs, long long bc_ns, long long bc_ts, int nchunks128, hipStream_t s);
+                          int batch, int dim, int seqlen, int io_dtype, long long z_bs,
+                          long long bc_bs, long long bc_ns, long long bc_ts, int nchunks128, int lpc, hipStream_t s);
+int scan_fwd_seq_bc_mode(const void* B, const void* C, int io_dtype, long long bc_bs, long long bc_ns, long long bc_ts);
 
-// The lane-per-channel kernel (scan_fwd_seq.hip) is taken from this many (batch, channel) rows on.
-constexpr long long kSeqMinRows = 98304;
-
-static bool seq_path_wanted(long long rows) {
-  long long min_rows = kSeqMinRows;
-  if (const char* e = getenv("SIMAMBA_SEQ_MIN_ROWS")) min_rows = atoll(e);   // tuning knobs (tools/bench_scan.py)
-  if (const char* e = getenv("SIMAMBA_SEQ_FWD")) return atoi(e) != 0 && rows >= min_rows;
-  return rows >= min_rows;
+// Kernel choice when the caller leaves it to the library (variant == SIMAMBA_SCAN_AUTO).  The lanes-per-channel
+// kernel (scan_fwd_seq.hip) issues 5 VALU per (row, step, state) against ~7 for the row-scan kernel, but a wave
+// covers 64 / lpc whole rows: it needs rows / (64 / lpc) waves to give every one of the 1024 SIMDs its 3 waves.
+static int auto_variant(long long rows) {
+  if (rows >= 3 * 1024 * 32) return SIMAMBA_SCAN_LPC2;      // >= 98 304 rows: two lanes per channel
+  // below that the row-scan kernel wins: measured at (64,768,1024,16) row-scan 316 us, LPC4 335 us, LPC2 366 us
+  return SIMAMBA_SCAN_ROWSCAN;
 }
 
 }  // namespace simamba
 
 using namespace simamba;
-
-extern "C" size_t simamba_scan_fwd_workspace_bytes(int, int, int, int) {
-  return 0;   // no forward variant needs scratch memory any more (ABI kept: callers may pass NULL / 0)
-}
 
 extern "C" int simamba_scan_num_chunks(int seqlen) {
   if (seqlen <= 64) return 1;
@@ -194,7 +190,7 @@ extern "C" int simamba_selective_scan_fwd(const void* u, const void* delta, cons
                                           float* last_state, int batch, int dim, int seqlen, int dstate,
                                           int io_dtype, int delta_softplus, long long z_bstride,
                                           long long bc_bstride, long long bc_nstride, long long bc_tstride,
-                                          void* workspace, size_t ws_bytes, void* stream) {
+                                          int variant, void* stream) {
   if (batch < 0 || dim <= 0 || seqlen < 0 || batch > 65535) return SIMAMBA_E_SHAPE;
   if (dstate < 1 || dstate > kMaxState) return SIMAMBA_E_DSTATE;
   if (io_dtype != SIMAMBA_F32 && io_dtype != SIMAMBA_BF16) return SIMAMBA_E_DTYPE;
@@ -215,13 +211,26 @@ extern "C" int simamba_selective_scan_fwd(const void* u, const void* delta, cons
   a.vec = ((seqlen * esz) % 16 == 0) && aligned16(u) && aligned16(delta) && aligned16(out) &&
           (!z || (aligned16(z) && (a.z_bs * esz) % 16 == 0));
   hipStream_t s = static_cast<hipStream_t>(stream);
-  (void)workspace; (void)ws_bytes;
+  if (variant != SIMAMBA_SCAN_AUTO && variant != SIMAMBA_SCAN_ROWSCAN && variant != SIMAMBA_SCAN_LPC2 &&
+      variant != SIMAMBA_SCAN_LPC4)
+    return SIMAMBA_E_VARIANT;
   const long long rows = static_cast<long long>(batch) * dim;
-  if (dstate == kMaxState && a.vec && seq_path_wanted(rows) && rows * seqlen < (1ll << 30) &&
-      static_cast<long long>(batch) * a.z_bs < (1ll << 30) && (reinterpret_cast<uintptr_t>(A) & 15u) == 0 &&
-      a.bc_ns >= 0 && a.bc_ts >= 0 && (kMaxState - 1) * a.bc_ns + (seqlen - 1) * a.bc_ts < (1ll << 30))
+  // what the lanes-per-channel kernel assumes: 16 states, softplus on (the only form the reference's mixer uses),
+  // pack-aligned rows and B / C, 32-bit byte offsets
+  const bool seq_ok = dstate == kMaxState && delta_softplus && a.vec && rows * seqlen < (1ll << 30) &&
+                      scan_fwd_seq_bc_mode(B, C, io_dtype, a.bc_bs, a.bc_ns, a.bc_ts) != 0 &&
+                      static_cast<long long>(batch) * a.z_bs < (1ll << 30) &&
+                      (reinterpret_cast<uintptr_t>(A) & 15u) == 0 && a.bc_ns >= 0 && a.bc_ts >= 0 &&
+                      (kMaxState - 1) * a.bc_ns + (seqlen - 1) * a.bc_ts < (1ll << 30);
+  int v = variant == SIMAMBA_SCAN_AUTO ? auto_variant(rows) : variant;
+  if (v != SIMAMBA_SCAN_ROWSCAN && !seq_ok) {
+    if (variant != SIMAMBA_SCAN_AUTO) return SIMAMBA_E_VARIANT;     // an explicit request the shape cannot take
+    v = SIMAMBA_SCAN_ROWSCAN;
+  }
+  if (v != SIMAMBA_SCAN_ROWSCAN)
     return scan_fwd_seq_dispatch(u, delta, A, B, C, D, z, delta_bias, out, x_ckpt, last_state, batch, dim, seqlen,
-                                 io_dtype, delta_softplus, a.z_bs, a.bc_bs, a.bc_ns, a.bc_ts, a.nchunks, s);
+                                 io_dtype, a.z_bs, a.bc_bs, a.bc_ns, a.bc_ts, a.nchunks,
+                                 v == SIMAMBA_SCAN_LPC2 ? 2 : 4, s);
   // channels per workgroup: amortise the (B_t,C_t) staging, but keep >= ~3 workgroups per CU
   int passes = 4;
   while (passes > 1 && static_cast<long long>(batch) * ((dim + 16 * passes - 1) / (16 * passes)) < 768) passes >>= 1;

@@ -1,42 +1,37 @@
-// Selective-scan forward, "lane per channel" form, for gfx950.
+// Selective-scan forward, "lanes per channel" form, for gfx950.
 //
-// Used when there are enough (batch, channel) rows to fill the chip with kLPC lanes per row
-// (kLPC = 1, 2 or 4 adjacent lanes share a channel and split its 16 states): the recurrence
-// h_t = a_t h_{t-1} + x_t B_t then needs only mul + exp2 + mul + fma + fma per (row, t, state) -- 5 VALU
-// issues against ~9 for the row-scan form of scan_fwd.hip.  tools/valu_probe.hip prices that group at
-// 8.6 - 10 ns per wave and SIMD (v_exp_f32 is quarter rate and does not overlap the FMA pipe).
-// Measured at 256 x 768 x 128 x 16 fp32: 150 us (row-scan kernel: 165 us).  What bounds it is no longer the
-// recurrence: built with -DSIMAMBA_SEQ_SKIP_B (phases A and C only) the kernel still takes 130 us, because a
-// chunk touches 64 B of every 128-byte line and the other half is requested one chunk (~16 us, ~9 MB of
-// traffic per XCD) later, after the line has left the 4 MB L2 -- PMC FETCH_SIZE shows 2x the algorithmic
-// read bytes.  Full-line (32-step) chunks would need 2x the LDS or registers per wave and cost the occupancy
-// the VALU side needs; DESIGN.md section 4.1 has the numbers.
+// kLPC = 2 or 4 adjacent lanes share a channel and split its 16 states, so the recurrence
+// h_t = a_t h_{t-1} + x_t B_t costs mul + exp2 + mul + fma + fma per (row, t, state) -- 5 VALU issues against ~9 for
+// the row-scan form of scan_fwd.hip -- and a wave walks time sequentially over R = 64 / kLPC channels of one sample.
 //
-//   * waves are independent (no workgroup barrier): a wave owns R = 64 / kLPC consecutive channels of one
-//     sample and walks time in chunks of 16 steps through wave-private LDS tiles;
-//   * phase A (lane <-> 4 time steps of a row): 16-byte coalesced loads of delta / u, softplus, into the
-//     tiles tD = delta, tU = u, [R][16] floats with the 16-byte column groups XOR-swizzled by (row >> 2) & 3
-//     so both the row-wise reads of phase B and the pack-wise accesses of A / C are conflict-free without
-//     padding; the chunk's B_t | C_t (16 steps x 32 floats) is staged next to them straight from the
-//     strided B / C operands (no packing pass, no workspace);
-//   * phase B (lane <-> channel, NS = 16 / kLPC states in VGPRs): per step one ds_read_b128 each of B_t and
-//     C_t at address 16 * (lane & 3): VGPR j then holds entry 4p + j at quad position p, identically in all
-//     16 quads.  With one lane per channel the operand "B_t[4a + j] for every lane" is that VGPR read through
-//     DPP quad_perm:[a,a,a,a] inside the multiply -- the broadcast costs no instruction, no SGPR, no scalar
-//     cache traffic (a first version fed B_t / C_t through s_load: tools/smem_probe.hip measures 30 - 50 ns
-//     per scalar-cache miss and CU, which capped that kernel at 163 us).  With two lanes per channel the
-//     perm is [a,a+2,a,a+2] (the odd lane gets entry 8 + 4a + j), with four it is the identity (plain
-//     operand).  The kLPC partial y_t are combined with 1 - 2 DPP quad adds per step;
+// Memory side (what round 1's 16-step version got wrong): a chunk is 32 steps = ONE WHOLE 128-byte line of an fp32
+// row.  With 16-step chunks every load touched 64 B of a line and came back for the other half one chunk later,
+// after the line had left L2: PMC FETCH_SIZE showed 1.69x the algorithmic bytes and the kernel took 130 us with
+// the recurrence compiled out.  tools/mem_probe.hip prices the access shapes on the box (403 MB in + out, no
+// compute): 16 rows x 64 B per instruction 103 us, 8 rows x 128 B 77 us, a plain linear stream 76 us.
+//
+//   * waves are independent (no workgroup barrier); a wave owns wave-private LDS tiles tD = softplus(delta),
+//     tU = u (overwritten by y), [R][32] floats, 16-byte column groups XOR-swizzled by (row >> 1) & 7: the pack-wise
+//     accesses of phases A / C (8 lanes x 16 B = one row) and the row-wise reads of phase B (ds_read_b128, one row
+//     per kLPC lanes) are both conflict-free without padding; plus the chunk's B_t | C_t (32 steps x 32 floats),
+//     staged straight from the strided operands with 16-byte loads when their layout allows;
+//   * phase A (lane <-> one 16-byte pack of a row): coalesced loads of delta / u, softplus, into the tiles;
+//   * phase B (lane <-> channel, NS = 16 / kLPC states in VGPRs): per step one ds_read_b128 each of B_t and C_t at
+//     address 16 * (lane & 3): VGPR j then holds entry 4p + j at quad position p, identically in all 16 quads, and
+//     "B_t[n] for this lane's state n" is that VGPR read through DPP quad_perm inside v_mul / v_fmac ([a,a+2,a,a+2]
+//     with two lanes per channel, the identity with four) -- no broadcast instruction, no SGPR, no scalar-cache
+//     traffic.  tools/scan_probe.hip prices the alternatives (LDS broadcast reads with plain VALU operands, one or
+//     two channels per lane): none is faster than this at 3 - 4 waves per SIMD.  The kLPC partial y_t are combined
+//     with 1 - 2 DPP quad adds per step;
 //   * y_t overwrites u_t in the tile; phase C (same lane <-> pack map as A): y * silu(z), 16-byte stores;
-//   * the next chunk's global loads are issued right after phase A, so HBM latency hides under phase B.
-#include <cstdlib>
+//   * the next chunk's delta / u loads are issued right after phase A and fly during the whole recurrence.
 #include "scan_common.h"
 
 namespace simamba {
 
-constexpr int kSeqTC = 16;                 // timesteps per chunk
+constexpr int kSeqTC = 32;                 // timesteps per chunk: one 128-byte line of an fp32 row
 constexpr int kSeqThreads = 256;           // 4 independent waves
-constexpr int kBcPitch = 36;               // floats per staged B_t | C_t row (32 + 4: staging writes 2-way, not 16-way)
+constexpr int kBcPitch = 36;               // floats per staged B_t | C_t row (32 + 4)
 
 struct SeqArgs {
   const void* u;
@@ -51,12 +46,12 @@ struct SeqArgs {
   float* x_ckpt;
   float* last_state;
   int batch, dim, seqlen, nchunks128;
-  int softplus;
+  int bc_mode;                             // 1 time-major packs of B / C, 2 token-major packs
   long long z_bs;
   long long bc_bs, bc_ns, bc_ts;
 };
 
-// ---- multiply / multiply-accumulate with a quad-broadcast first operand ------------------------------------
+// ---- multiply / multiply-accumulate with a quad-selected first operand -----------------------------------------
 // The DPP-selected source is always a VGPR written by ds_read (never by a VALU op), so the
 // "VALU write -> DPP read: 2 wait states" hazard does not apply and no s_nop padding is needed.  Plain
 // (non-volatile) asm: pure functions of their operands, free for the scheduler to interleave.
@@ -71,27 +66,24 @@ template <int P> __device__ __forceinline__ void fmac_q(float& acc, float s, flo
   template <> __device__ __forceinline__ void fmac_q<P>(float& acc, float s, float x) {                        \
     asm("v_fmac_f32_dpp %0, %1, %2 quad_perm:" PERM " row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(s), "v"(x)); \
   }
-SIMAMBA_QUAD_OPS(0, "[0,0,0,0]")
-SIMAMBA_QUAD_OPS(1, "[1,1,1,1]")
-SIMAMBA_QUAD_OPS(2, "[2,2,2,2]")
-SIMAMBA_QUAD_OPS(3, "[3,3,3,3]")
-SIMAMBA_QUAD_OPS(4, "[0,2,0,2]")
-SIMAMBA_QUAD_OPS(5, "[1,3,1,3]")
+SIMAMBA_QUAD_OPS(0, "[0,2,0,2]")
+SIMAMBA_QUAD_OPS(1, "[1,3,1,3]")
 #undef SIMAMBA_QUAD_OPS
 
 // One aligned 4-element pack per lane (16 B fp32 / 8 B bf16).  The dispatcher only takes this kernel when
 // rows are pack-aligned (L % 4 == 0 for fp32, L % 8 == 0 for bf16), so a pack is either entirely inside the
-// sequence or entirely outside: out-of-range packs read element 0 of the tensor and are zeroed -- no
-// per-element guards, no divergent branches.
+// sequence or entirely outside.  A pack beyond the end of the sequence (last chunk of a ragged L) re-reads the
+// FIRST pack of its own row -- valid memory, finite whenever the row is -- and is neutralised once per pack, not
+// per element: its delta gets a bias of -1e30, which softplus maps to exactly 0 (a_t = 1, x_t = 0: the state
+// passes through), and its outputs are not stored.  No per-element guards, no divergent branches.
 // Addressing is "uniform base pointer + 32-bit BYTE offset" throughout (the dispatcher guarantees every tensor
 // spans < 4 GiB): global_load/store then take the base in SGPRs and one VGPR of offset, instead of a 64-bit
 // VGPR address per access that the compiler hoists out of the chunk loop and spills.
 template <typename T>
-__device__ __forceinline__ void load4(const T* __restrict__ base, unsigned boff, bool ok, float (&v)[4]) {
-  const Pack<T, 4> pk =
-      *reinterpret_cast<const Pack<T, 4>*>(reinterpret_cast<const char*>(base) + (ok ? boff : 0u));
+__device__ __forceinline__ void load4(const T* __restrict__ base, unsigned boff, float (&v)[4]) {
+  const Pack<T, 4> pk = *reinterpret_cast<const Pack<T, 4>*>(reinterpret_cast<const char*>(base) + boff);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) v[i] = ok ? to_f32<T>(pk.v[i]) : 0.f;
+  for (int i = 0; i < 4; ++i) v[i] = to_f32<T>(pk.v[i]);
 }
 template <typename T>
 __device__ __forceinline__ void store4(T* __restrict__ base, unsigned boff, const float (&v)[4]) {
@@ -101,15 +93,27 @@ __device__ __forceinline__ void store4(T* __restrict__ base, unsigned boff, cons
   *reinterpret_cast<Pack<T, 4>*>(reinterpret_cast<char*>(base) + boff) = pk;
 }
 
-// float offset of 16-byte column group g of a tile row
-__device__ __forceinline__ int tile_off(int row, int g) { return row * kSeqTC + 4 * (g ^ ((row >> 2) & 3)); }
+// softplus(x) with x handed over as x2 = x * log2(e) (the caller folds the scale into one fma with the bias):
+// 2 transcendentals + 7 plain ops, branch-free.  Above torch's threshold (x > 20) the result is x itself (and the
+// exp2 overflow beyond x ~ 88 never shows); below -15 the series log(1 + e) = e keeps the relative accuracy that
+// 1 + e loses.  x2 = -inf-like (-1e30 from a padded pack) gives e = 0 and exactly 0.
+__device__ __forceinline__ float softplus_log2(float x2) {
+  const float e = fast_exp2(x2);
+  float sp = fast_log2(1.f + e) * kLn2;
+  sp = (x2 < -15.f * kLog2e) ? e : sp;
+  return (x2 > 20.f * kLog2e) ? x2 * kLn2 : sp;
+}
+
+// float offset of 16-byte column group g (0..7) of a tile row
+__device__ __forceinline__ int tile_off(int row, int g) { return row * kSeqTC + 4 * (g ^ ((row >> 1) & 7)); }
 
 template <int kLPC> struct SeqCfg {
   static constexpr int NS = kMaxState / kLPC;    // states per lane
   static constexpr int R = 64 / kLPC;            // channels per wave
-  static constexpr int kPacks = 4 / kLPC;        // 4-step packs per lane, tensor and chunk
+  static constexpr int kPacks = R / 8;           // 4-step packs per lane, tensor and chunk (8 packs = one row)
   static constexpr int kTileFloats = 2 * R * kSeqTC + kSeqTC * kBcPitch;
-  static constexpr int kWaves = kLPC == 1 ? 3 : 4;   // waves per SIMD the register budget targets (6 spills)
+  // waves per SIMD: what the LDS footprint admits (4 waves x kTileFloats x 4 B per workgroup, 160 KiB per CU)
+  static constexpr int kWaves = kLPC == 2 ? 3 : 4;
 };
 
 template <typename T, bool kHasZ, int kLPC>
@@ -126,7 +130,7 @@ __global__ __launch_bounds__(kSeqThreads, SeqCfg<kLPC>::kWaves) void scan_fwd_se
   if (ch_base >= D) return;                                            // whole wave idle (no barriers here)
   float* tD = &sMem[wave][0];
   float* tU = tD + R * kSeqTC;
-  float* tBC = tU + R * kSeqTC;            // [16 steps][B_t(16) | C_t(16) | pad(4)]
+  float* tBC = tU + R * kSeqTC;            // [32 steps][B_t(16) | C_t(16) | pad(4)]
 
   // ---- phase B identity: channel lane / kLPC, states NS * (lane % kLPC) .. + NS --------------------------
   const int rowB = lane / kLPC;
@@ -145,8 +149,8 @@ __global__ __launch_bounds__(kSeqThreads, SeqCfg<kLPC>::kWaves) void scan_fwd_se
   // the skip term D * u_t enters the partial sum of the first lane of a channel only
   const float Dl = (p.D && (lane % kLPC) == 0) ? p.D[d_own] : 0.f;
 
-  // ---- phase A / C identity: pack pk = lane + 64 j covers row pk / 4, steps 4 (pk % 4) .. + 4 -------------
-  const int q = lane & 3;
+  // ---- phase A / C identity: pack pk = lane + 64 j covers row pk / 8, steps 4 (pk % 8) .. + 4 -------------
+  const int q = lane & 7;
   float biasA[kPacks];
   unsigned rowoff[kPacks];
   // byte offsets off one base pointer per tensor; z sits at a wave-uniform distance from u (its batch stride
@@ -155,8 +159,8 @@ __global__ __launch_bounds__(kSeqThreads, SeqCfg<kLPC>::kWaves) void scan_fwd_se
   const unsigned zdelta = (static_cast<unsigned>(b * p.z_bs) - static_cast<unsigned>(b) * D * L) * kEsz;
 #pragma unroll
   for (int j = 0; j < kPacks; ++j) {
-    const int dA = min(ch_base + (lane >> 2) + 16 * j, D - 1);
-    biasA[j] = p.delta_bias ? p.delta_bias[dA] : 0.f;
+    const int dA = min(ch_base + (lane >> 3) + 8 * j, D - 1);
+    biasA[j] = (p.delta_bias ? p.delta_bias[dA] : 0.f) * kLog2e;    // softplus works in the log2 domain
     rowoff[j] = ((static_cast<unsigned>(b) * D + dA) * L + 4 * q) * kEsz;
   }
   const T* __restrict__ ug = static_cast<const T*>(p.u);
@@ -164,43 +168,61 @@ __global__ __launch_bounds__(kSeqThreads, SeqCfg<kLPC>::kWaves) void scan_fwd_se
   const T* __restrict__ zg = static_cast<const T*>(p.z);
   T* __restrict__ og = static_cast<T*>(p.out);
 
-  // ---- B_t | C_t staging identity: 512 scalars per chunk, 8 per lane, consecutive lanes on the contiguous
-  // axis of the operand (time for (B,N,L) tensors, state for token-major views of the x_proj output) ---------
+  // ---- B_t | C_t staging: 32 steps x 16 states per tensor and chunk = 2 packs of 4 per lane and tensor.
+  //   time-major (element (n, t) at n * ns + t): a pack = 4 steps of one state, transposed into the [t][n] image by
+  //     4 ds_write_b32;
+  //   token-major (state stride 1: the mixer's x_proj output): a pack = 4 states of one step, one ds_write_b128.
+  // Other strides / alignments never reach this kernel (the dispatcher sends them to the row-scan kernel).
   const T* __restrict__ Bg = static_cast<const T*>(p.B) + static_cast<long long>(b) * p.bc_bs;
   const T* __restrict__ Cg = static_cast<const T*>(p.C) + static_cast<long long>(b) * p.bc_bs;
-  const bool token_major = p.bc_ns == 1;
+  const bool tok = p.bc_mode == 2;
   const int bc_ns = static_cast<int>(p.bc_ns), bc_ts = static_cast<int>(p.bc_ts);
   // `lane_v` is an opaque copy of the lane id refreshed once per chunk: index arithmetic derived from it is
-  // recomputed per chunk (a few VALU ops) instead of being hoisted into ~40 loop-invariant VGPRs and spilled
+  // recomputed per chunk (a few VALU ops) instead of being hoisted into loop-invariant VGPRs and spilled
   int lane_v = lane;
-  auto bc_index = [&](int i, int& n, int& t) {
-    const int e = lane_v + 64 * i;                     // 0 .. 255
-    n = token_major ? (e & 15) : (e >> 4);
-    t = token_major ? (e >> 4) : (e & 15);
-  };
-  float bcv[2][4];
+  // pack e = lane + 64 i (i = 0, 1): time-major -> state e >> 3, steps 4 (e & 7) ..; token-major -> step e >> 2,
+  // states 4 (e & 3) ..  Packs beyond the sequence re-read step 0; their steps carry delta = 0, x = 0, so whatever
+  // they hold is multiplied away.
+  float bcv[2][2][4];
   auto issue_bc = [&](int t0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      int n, tl;
-      bc_index(i, n, tl);
-      const int t = t0 + tl;
-      const bool ok = t < L;
-      const unsigned o = ok ? static_cast<unsigned>(n * bc_ns + t * bc_ts) * kEsz : 0u;   // bytes, < 2^32
-      const float vb = to_f32<T>(*reinterpret_cast<const T*>(reinterpret_cast<const char*>(Bg) + o));
-      const float vc = to_f32<T>(*reinterpret_cast<const T*>(reinterpret_cast<const char*>(Cg) + o));
-      bcv[0][i] = ok ? vb : 0.f;
-      bcv[1][i] = ok ? vc : 0.f;
+    for (int i = 0; i < 2; ++i) {
+      const int e = lane_v + 64 * i;
+      const int n = tok ? 4 * (e & 3) : (e >> 3);
+      const int tl = tok ? (e >> 2) : 4 * (e & 7);
+      const int t = (t0 + tl < L) ? t0 + tl : 0;
+      const unsigned o = static_cast<unsigned>(n * bc_ns + t * bc_ts) * kEsz;   // bytes, < 2^32
+      load4<T>(Bg, o, bcv[0][i]);
+      load4<T>(Cg, o, bcv[1][i]);
+    }
+  };
+  auto stage_bc_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int e = lane_v + 64 * i;
+      if (tok) {
+        float* dst = tBC + (e >> 2) * kBcPitch + 4 * (e & 3);
+        *reinterpret_cast<float4*>(dst) = make_float4(bcv[0][i][0], bcv[0][i][1], bcv[0][i][2], bcv[0][i][3]);
+        *reinterpret_cast<float4*>(dst + 16) = make_float4(bcv[1][i][0], bcv[1][i][1], bcv[1][i][2], bcv[1][i][3]);
+      } else {
+        float* dst = tBC + 4 * (e & 7) * kBcPitch + (e >> 3);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          dst[k * kBcPitch] = bcv[0][i][k];
+          dst[k * kBcPitch + 16] = bcv[1][i][k];
+        }
+      }
     }
   };
 
   float dv[kPacks][4], uv[kPacks][4], zv[kPacks][4];
   auto issue_loads = [&](int t0) {
-    const bool ok = t0 + 4 * q < L;
+    // beyond the end of the sequence: the row's first pack (rowoff already points 4 q steps into the row)
+    const unsigned toff = (t0 + 4 * q < L) ? t0 * kEsz : 0u - 4u * q * kEsz;
 #pragma unroll
     for (int j = 0; j < kPacks; ++j) {
-      load4<T>(dg, rowoff[j] + t0 * kEsz, ok, dv[j]);
-      load4<T>(ug, rowoff[j] + t0 * kEsz, ok, uv[j]);
+      load4<T>(dg, rowoff[j] + toff, dv[j]);
+      load4<T>(ug, rowoff[j] + toff, uv[j]);
     }
   };
 
@@ -210,73 +232,47 @@ __global__ __launch_bounds__(kSeqThreads, SeqCfg<kLPC>::kWaves) void scan_fwd_se
   for (int c = 0; c < nchunks; ++c) {
     const int t0 = c * kSeqTC;
     asm volatile("" : "+v"(lane_v));
-    const int qv = lane_v & 3, prow = lane_v >> 2;
+    const int qv = lane_v & 7, prow = lane_v >> 3;
     const bool in_seq = t0 + 4 * qv < L;
     // ---- phase A: softplus(delta), u and the chunk's B | C into the tiles ------------------------------------
 #pragma unroll
     for (int j = 0; j < kPacks; ++j) {
+      const float b2 = in_seq ? biasA[j] : -1e30f;            // padded pack: softplus -> 0, the identity map
       float dl[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        float x = dv[j][i] + biasA[j];
-        x = p.softplus ? softplus_f(x) : x;
-        dl[i] = in_seq ? x : 0.f;                  // padded packs: identity map (and u = 0: no input)
-      }
-      const int o = tile_off(prow + 16 * j, qv);
+      for (int i = 0; i < 4; ++i) dl[i] = softplus_log2(fmaf(dv[j][i], kLog2e, b2));
+      const int o = tile_off(prow + 8 * j, qv);
       *reinterpret_cast<float4*>(tD + o) = make_float4(dl[0], dl[1], dl[2], dl[3]);
       *reinterpret_cast<float4*>(tU + o) = make_float4(uv[j][0], uv[j][1], uv[j][2], uv[j][3]);
     }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      int n, tl;
-      bc_index(i, n, tl);
-      tBC[tl * kBcPitch + n] = bcv[0][i];
-      tBC[tl * kBcPitch + 16 + n] = bcv[1][i];
-    }
-    // dv / uv are dead after phase A: with registers to spare (kLPC = 1) the next chunk's loads fly during
-    // the whole recurrence, otherwise they are requested after it (6 resident waves cover the latency)
-    if (kLPC == 1 && c + 1 < nchunks) issue_loads(t0 + kSeqTC);
+    stage_bc_tile();
+    // dv / uv are dead after phase A: the next chunk's loads fly during the whole recurrence
+    if (c + 1 < nchunks) issue_loads(t0 + kSeqTC);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
     // ---- phase B: the recurrence ------------------------------------------------------------------------------
-    // LDS reads run one step (B_t | C_t) / one group (delta, u) ahead of their use; the sched_barriers keep
-    // hipcc from sinking them back next to the consumer (it did, exposing ~200 cycles of LDS latency per step)
-    float4 d4n, u4n;
-    if (kLPC == 1) {
-      d4n = *reinterpret_cast<const float4*>(tD + tile_off(rowB, 0));
-      u4n = *reinterpret_cast<const float4*>(tU + tile_off(rowB, 0));
-    }
-    float4 b4n = *reinterpret_cast<const float4*>(tBC + 4 * q);
-    float4 c4n = *reinterpret_cast<const float4*>(tBC + 16 + 4 * q);
-#ifdef SIMAMBA_SEQ_SKIP_B        // timing experiment only: phases A and C without the recurrence
-#pragma unroll 1
-    for (int g = 0; g < 0; ++g) {
-#else
+    // LDS reads run one step (B_t | C_t) ahead of their use; the sched_barriers keep hipcc from sinking them
+    // back next to the consumer (it did, exposing ~200 cycles of LDS latency per step)
+    const int q3 = lane_v & 3;
+    float4 b4n = *reinterpret_cast<const float4*>(tBC + 4 * q3);
+    float4 c4n = *reinterpret_cast<const float4*>(tBC + 16 + 4 * q3);
 #pragma unroll 1
     for (int g = 0; g < kSeqTC / 4; ++g) {
-#endif
       const int o = tile_off(rowB, g);
-      if (kLPC != 1) {
-        d4n = *reinterpret_cast<const float4*>(tD + o);
-        u4n = *reinterpret_cast<const float4*>(tU + o);
-      }
-      const float dl[4] = {d4n.x, d4n.y, d4n.z, d4n.w};
-      const float uu[4] = {u4n.x, u4n.y, u4n.z, u4n.w};
-      if (kLPC == 1) {
-        const int on = tile_off(rowB, (g + 1) & 3);      // wraps on the last group: harmless re-read
-        d4n = *reinterpret_cast<const float4*>(tD + on);
-        u4n = *reinterpret_cast<const float4*>(tU + on);
-      }
+      const float4 d4 = *reinterpret_cast<const float4*>(tD + o);
+      const float4 u4 = *reinterpret_cast<const float4*>(tU + o);
+      const float dl[4] = {d4.x, d4.y, d4.z, d4.w};
+      const float uu[4] = {u4.x, u4.y, u4.z, u4.w};
       float yy[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const float vB[4] = {b4n.x, b4n.y, b4n.z, b4n.w};
         const float vC[4] = {c4n.x, c4n.y, c4n.z, c4n.w};
         {
-          const int tn = (4 * g + i + 1) & (kSeqTC - 1);
-          b4n = *reinterpret_cast<const float4*>(tBC + tn * kBcPitch + 4 * q);
-          c4n = *reinterpret_cast<const float4*>(tBC + tn * kBcPitch + 16 + 4 * q);
+          const int tn = (4 * g + i + 1) & (kSeqTC - 1);      // wraps on the last step: harmless re-read
+          b4n = *reinterpret_cast<const float4*>(tBC + tn * kBcPitch + 4 * q3);
+          c4n = *reinterpret_cast<const float4*>(tBC + tn * kBcPitch + 16 + 4 * q3);
         }
         __builtin_amdgcn_sched_barrier(0);
         const float xx = dl[i] * uu[i];
@@ -288,26 +284,19 @@ __global__ __launch_bounds__(kSeqThreads, SeqCfg<kLPC>::kWaves) void scan_fwd_se
             const int n = 4 * a + j;
             float& y = ys[j & 1];
             const float e = fast_exp2(dl[i] * A2[n]);
-            if constexpr (kLPC == 4) {
+            if constexpr (kLPC == 4) {                   // quad position p holds entries 4p .. 4p+3: the lane's own
               h[n] = fmaf(e, h[n], xx * vB[j]);
               y = fmaf(h[n], vC[j], y);
-            } else {
-              constexpr int kSel = kLPC == 1 ? 0 : 4;
+            } else {                                     // even lanes: entries 4a + j, odd lanes: 8 + 4a + j
               float xb;
-              if (a == 0) xb = mul_q<kSel + 0>(vB[j], xx);
-              else if (a == 1) xb = mul_q<kSel + 1>(vB[j], xx);
-              else if (a == 2) xb = mul_q<(kLPC == 1 ? 2 : 0)>(vB[j], xx);
-              else xb = mul_q<(kLPC == 1 ? 3 : 0)>(vB[j], xx);
+              if (a == 0) xb = mul_q<0>(vB[j], xx); else xb = mul_q<1>(vB[j], xx);
               h[n] = fmaf(e, h[n], xb);
-              if (a == 0) fmac_q<kSel + 0>(y, vC[j], h[n]);
-              else if (a == 1) fmac_q<kSel + 1>(y, vC[j], h[n]);
-              else if (a == 2) fmac_q<(kLPC == 1 ? 2 : 0)>(y, vC[j], h[n]);
-              else fmac_q<(kLPC == 1 ? 3 : 0)>(y, vC[j], h[n]);
+              if (a == 0) fmac_q<0>(y, vC[j], h[n]); else fmac_q<1>(y, vC[j], h[n]);
             }
           }
         }
         float y = ys[0] + ys[1];
-        if (kLPC >= 2) y += dpp<DPP_QUAD_XOR1>(0.f, y);
+        y += dpp<DPP_QUAD_XOR1>(0.f, y);
         if (kLPC == 4) y += dpp<DPP_QUAD_XOR2>(0.f, y);
         yy[i] = y;
         __builtin_amdgcn_sched_barrier(0);
@@ -320,12 +309,9 @@ __global__ __launch_bounds__(kSeqThreads, SeqCfg<kLPC>::kWaves) void scan_fwd_se
     // recurrence; the latency hides under phase C and the other resident waves
     if (kHasZ) {
 #pragma unroll
-      for (int j = 0; j < kPacks; ++j) load4<T>(zg, rowoff[j] + zdelta + t0 * kEsz, in_seq, zv[j]);
+      for (int j = 0; j < kPacks; ++j) load4<T>(zg, rowoff[j] + zdelta + (in_seq ? t0 * kEsz : 0u - 4u * qv * kEsz), zv[j]);
     }
-    if (c + 1 < nchunks) {
-      issue_bc(t0 + kSeqTC);
-      if (kLPC != 1) issue_loads(t0 + kSeqTC);
-    }
+    if (c + 1 < nchunks) issue_bc(t0 + kSeqTC);
     // state checkpoints at the 128-step boundaries the backward uses, and the final state
     const int tend = t0 + kSeqTC;
     if (own_valid) {
@@ -348,7 +334,7 @@ __global__ __launch_bounds__(kSeqThreads, SeqCfg<kLPC>::kWaves) void scan_fwd_se
     // ---- phase C: gate and store in load order ----------------------------------------------------------------
 #pragma unroll
     for (int j = 0; j < kPacks; ++j) {
-      const float4 y4 = *reinterpret_cast<const float4*>(tU + tile_off(prow + 16 * j, qv));
+      const float4 y4 = *reinterpret_cast<const float4*>(tU + tile_off(prow + 8 * j, qv));
       const float yv[4] = {y4.x, y4.y, y4.z, y4.w};
       float o[4];
 #pragma unroll
@@ -357,7 +343,7 @@ __global__ __launch_bounds__(kSeqThreads, SeqCfg<kLPC>::kWaves) void scan_fwd_se
         if (kHasZ) v = v * zv[j][i] * sigmoid_f(zv[j][i]);
         o[i] = v;
       }
-      if (in_seq && ch_base + prow + 16 * j < D) store4<T>(og, rowoff[j] + t0 * kEsz, o);
+      if (in_seq && ch_base + prow + 8 * j < D) store4<T>(og, rowoff[j] + t0 * kEsz, o);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -374,40 +360,39 @@ static void launch_seq_lpc(const SeqArgs& a, hipStream_t s) {
     hipLaunchKernelGGL((scan_fwd_seq_kernel<T, false, kLPC>), grid, dim3(kSeqThreads), 0, s, a);
 }
 
-// lanes per channel: one while that still gives every one of the 1024 SIMDs 3 waves, two below
-// (measured, fp32, MI355X: 256x768x128 150 us with 1 lane / 154 us with 2 / 176 us with 4;
-//  128x768x1024 607 us with 2 lanes / 687 us with 4 -- the row-scan kernel needs 165 us / 666 us)
-int seq_lanes_per_channel(long long rows) {
-  if (const char* e = getenv("SIMAMBA_SEQ_LPC")) {       // tuning knob (tools/bench_scan.py)
-    const int v = atoi(e);
-    if (v == 1 || v == 2 || v == 4) return v;
-  }
-  return rows >= 3 * 1024 * 64 ? 1 : 2;
+// How this kernel would read B and C: 1 = 16-byte (fp32) / 8-byte (bf16) packs along time (t is the unit-stride axis),
+// 2 = packs along the state (n is: the mixer's x_proj output), 0 = neither keeps a pack aligned -- such operands go
+// to the row-scan kernel, which gathers element by element.
+int scan_fwd_seq_bc_mode(const void* B, const void* C, int io_dtype, long long bc_bs, long long bc_ns, long long bc_ts) {
+  const size_t esz = io_dtype == SIMAMBA_F32 ? 4 : 2;
+  const uintptr_t pm = 4 * esz - 1;
+  if (((reinterpret_cast<uintptr_t>(B) | reinterpret_cast<uintptr_t>(C)) & pm) != 0 || bc_bs % 4 != 0) return 0;
+  if (bc_ts == 1 && bc_ns % 4 == 0) return 1;
+  if (bc_ns == 1 && bc_ts % 4 == 0) return 2;
+  return 0;
 }
 
-template <typename T>
-static int launch_seq(const SeqArgs& a, hipStream_t s) {
-  switch (seq_lanes_per_channel(static_cast<long long>(a.batch) * a.dim)) {
-    case 1: launch_seq_lpc<T, 1>(a, s); break;
-    case 2: launch_seq_lpc<T, 2>(a, s); break;
-    default: launch_seq_lpc<T, 4>(a, s); break;
-  }
-  return static_cast<int>(hipGetLastError());
-}
-
-// Entry used by simamba_selective_scan_fwd (scan_fwd.hip) when the shape qualifies.
+// Entry used by simamba_selective_scan_fwd (scan_fwd.hip) when the shape qualifies (16 states, softplus on,
+// pack-aligned rows and B / C, 32-bit byte offsets); lpc = 2 or 4.
 int scan_fwd_seq_dispatch(const void* u, const void* delta, const float* A, const void* B, const void* C, const float* D,
                           const void* z, const float* delta_bias, void* out, float* x_ckpt, float* last_state,
-                          int batch, int dim, int seqlen, int io_dtype, int delta_softplus, long long z_bs,
-                          long long bc_bs, long long bc_ns, long long bc_ts, int nchunks128, hipStream_t s) {
+                          int batch, int dim, int seqlen, int io_dtype, long long z_bs,
+                          long long bc_bs, long long bc_ns, long long bc_ts, int nchunks128, int lpc, hipStream_t s) {
   SeqArgs a{};
   a.u = u; a.delta = delta; a.z = z; a.out = out; a.A = A; a.D = D; a.delta_bias = delta_bias;
   a.B = B; a.C = C;
   a.x_ckpt = x_ckpt; a.last_state = last_state;
   a.batch = batch; a.dim = dim; a.seqlen = seqlen; a.nchunks128 = nchunks128;
-  a.softplus = delta_softplus; a.z_bs = z_bs;
+  a.z_bs = z_bs;
   a.bc_bs = bc_bs; a.bc_ns = bc_ns; a.bc_ts = bc_ts;
-  return io_dtype == SIMAMBA_F32 ? launch_seq<float>(a, s) : launch_seq<bf16_t>(a, s);
+  a.bc_mode = scan_fwd_seq_bc_mode(B, C, io_dtype, bc_bs, bc_ns, bc_ts);
+  if (a.bc_mode == 0) return SIMAMBA_E_VARIANT;
+  if (io_dtype == SIMAMBA_F32) {
+    if (lpc == 2) launch_seq_lpc<float, 2>(a, s); else launch_seq_lpc<float, 4>(a, s);
+  } else {
+    if (lpc == 2) launch_seq_lpc<bf16_t, 2>(a, s); else launch_seq_lpc<bf16_t, 4>(a, s);
+  }
+  return static_cast<int>(hipGetLastError());
 }
 
 }  // namespace simamba

@@ -120,13 +120,12 @@ class MambaInnerFn(torch.autograd.Function):
         x_ckpt = (torch.empty(Bsz, Dm, nchunks, N, device=dev, dtype=torch.float32)
                   if (need_grad and nchunks > 1) else None)
         y = torch.empty(Bsz, Dm, L, device=dev, dtype=io)
-        ws = _lib.scan_workspace(Bsz, Dm, L, N, dev)
         with torch.cuda.device(dev), _lib.timed("scan_fwd", dev):
             rc = lib.simamba_selective_scan_fwd(
                 x_conv.data_ptr(), delta.data_ptr(), Af.data_ptr(), Bv.data_ptr(), Cv.data_ptr(), _lib.ptr(Df),
                 z.data_ptr(), _lib.ptr(bf), y.data_ptr(), _lib.ptr(x_ckpt), None,
                 Bsz, Dm, L, N, code, 1, xbs, x_dbl.stride(0), 1, x_dbl.stride(1),
-                _lib.ptr(ws), 0 if ws is None else ws.numel(), stream)
+                _lib.current_scan_variant(), stream)
         _lib.check(rc, "simamba_selective_scan_fwd")
 
         out = _xw(y.transpose(1, 2), ow_c.t())                                         # (B, L, d)

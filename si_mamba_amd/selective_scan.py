@@ -62,14 +62,13 @@ class SelectiveScanFn(torch.autograd.Function):
                   if (needs_grad and nchunks > 1) else None)
         last = (torch.empty(batch, dim, N, device=u.device, dtype=torch.float32)
                 if return_last_state else None)
-        ws = _lib.scan_workspace(batch, dim, L, N, u.device)
         with torch.cuda.device(u.device), _lib.timed("scan_fwd", u.device):
             rc = lib.simamba_selective_scan_fwd(
                 _lib.ptr(uc), _lib.ptr(dc), _lib.ptr(Ac), _lib.ptr(Bc), _lib.ptr(Cc), _lib.ptr(Dc),
                 _lib.ptr(zc), _lib.ptr(bc), _lib.ptr(out), _lib.ptr(x_ckpt), _lib.ptr(last),
                 batch, dim, L, N, code, int(bool(delta_softplus)),
                 0 if zc is None else zc.stride(0), Bc.stride(0), Bc.stride(1), Bc.stride(2),
-                _lib.ptr(ws), 0 if ws is None else ws.numel(), _lib.stream_ptr(u.device))
+                _lib.current_scan_variant(), _lib.stream_ptr(u.device))
         _lib.check(rc, "simamba_selective_scan_fwd")
         ctx.delta_softplus = bool(delta_softplus)
         ctx.has = (D is not None, z is not None, delta_bias is not None)

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_version_strerror_and_chunks():
     lib = _lib.load()
-    assert lib.simamba_abi_version() == 5
+    assert lib.simamba_abi_version() == 6
     assert lib.simamba_strerror(0) == b"ok"
     assert b"dstate" in lib.simamba_strerror(-4)
     assert lib.simamba_scan_num_chunks(64) == 1
@@ -37,18 +37,20 @@ def test_version_strerror_and_chunks():
     assert lib.simamba_scan_num_chunks(129) == 2
     assert lib.simamba_scan_num_chunks(1024) == 8
     assert lib.simamba_spectral_workspace_bytes(4, 128) == 256 + 4 * 128 * 128 * 4
-    assert lib.simamba_scan_fwd_workspace_bytes(64, 768, 1024, 16) == 0          # no forward kernel needs scratch
-    assert lib.simamba_scan_fwd_workspace_bytes(256, 768, 128, 16) == 0
+    assert b"variant" in lib.simamba_strerror(-9)
 
 
 def test_argument_validation_precedes_any_launch():
     lib = _lib.load()
     n = None
     one = ctypes.c_void_p(16)   # never dereferenced: every call below fails validation first
-    assert lib.simamba_selective_scan_fwd(n, n, n, n, n, n, n, n, n, n, n, 1, 1, 1, 16, 0, 1, 0, 0, 0, 0, n, 0, n) == -1
-    assert lib.simamba_selective_scan_fwd(one, one, one, one, one, n, n, n, one, n, n, 1, 8, 8, 17, 0, 1, 0, 0, 0, 0, n, 0, n) == -4
-    assert lib.simamba_selective_scan_fwd(one, one, one, one, one, n, n, n, one, n, n, 1, 8, 8, 16, 7, 1, 0, 0, 0, 0, n, 0, n) == -3
-    assert lib.simamba_selective_scan_fwd(one, one, one, one, one, n, n, n, one, n, n, 0, 8, 8, 16, 0, 1, 0, 0, 0, 0, n, 0, n) == 0
+    assert lib.simamba_selective_scan_fwd(n, n, n, n, n, n, n, n, n, n, n, 1, 1, 1, 16, 0, 1, 0, 0, 0, 0, 0, n) == -1
+    assert lib.simamba_selective_scan_fwd(one, one, one, one, one, n, n, n, one, n, n, 1, 8, 8, 17, 0, 1, 0, 0, 0, 0, 0, n) == -4
+    assert lib.simamba_selective_scan_fwd(one, one, one, one, one, n, n, n, one, n, n, 1, 8, 8, 16, 7, 1, 0, 0, 0, 0, 0, n) == -3
+    assert lib.simamba_selective_scan_fwd(one, one, one, one, one, n, n, n, one, n, n, 0, 8, 8, 16, 0, 1, 0, 0, 0, 0, 0, n) == 0
+    # an unknown kernel variant, and an explicit lanes-per-channel request the shape cannot take (dstate != 16)
+    assert lib.simamba_selective_scan_fwd(one, one, one, one, one, n, n, n, one, n, n, 1, 8, 8, 16, 0, 1, 0, 0, 0, 0, 3, n) == -9
+    assert lib.simamba_selective_scan_fwd(one, one, one, one, one, n, n, n, one, n, n, 1, 8, 8, 8, 0, 1, 0, 0, 0, 0, 2, n) == -9
     assert lib.simamba_causal_conv1d_fwd(one, one, n, one, 1, 8, 8, 5, 1, 0, 0, n) == -5
     assert lib.simamba_laplacian_topk(one, n, n, n, n, n, 1, 129, 4, 0, n) == -7
     assert lib.simamba_knn_graph(one, one, n, 0, 1, 16, 3, 16, 1.0, 0, n) == -7

@@ -239,31 +239,35 @@ def test_scan_backward_full_size_reductions(shape, dtype, device):
     assert torch.isfinite(nrm).all() and (nrm > 0.25 * nrm[bs].min()).all() and (nrm < 4 * nrm[bs].max()).all()
 
 
-# ---- the one-lane-per-channel forward (taken when batch*dim >= 98304 and rows are pack-aligned) ----------
-@pytest.mark.parametrize("L,dtype,split", [(16, torch.float32, 2), (40, torch.float32, 1), (132, torch.float32, 2),
-                                           (260, torch.float32, 4), (260, torch.float32, 1),
+# ---- the lanes-per-channel forward (the library's choice from 32 768 rows on; forced here through the ABI's variant) --
+@pytest.mark.parametrize("L,dtype,split", [(16, torch.float32, 2), (40, torch.float32, 4), (132, torch.float32, 2),
+                                           (260, torch.float32, 4), (260, torch.float32, 2), (32, torch.float32, 2),
                                            (128, torch.float32, 0), (136, torch.bfloat16, 2),
-                                           (264, torch.bfloat16, 4)])
-def test_scan_seq_kernel_path(L, dtype, split, device, monkeypatch):
+                                           (264, torch.bfloat16, 4), (1024, torch.float32, 4)])
+def test_scan_seq_kernel_path(L, dtype, split, device):
     """Same parity bar as the row-scan kernel, on a row subset (the full tensor is too slow for the CPU
-    oracle), including the chunk checkpoints it hands to the backward (L > 128) and the final state."""
+    oracle), including the chunk checkpoints it hands to the backward (L > 128) and the final state.
+    ``split``: lanes per channel (a channel's 16 states split over 2 or 4 adjacent lanes); 0 = the library's choice."""
     from si_mamba_amd import _lib, selective_scan_fn
-    monkeypatch.setenv("SIMAMBA_SEQ_FWD", "1")
-    if split:      # a channel's 16 states are split over `split` adjacent lanes; 0 = the dispatcher's own choice
-        monkeypatch.setenv("SIMAMBA_SEQ_LPC", str(split))
-    B, D, N = 128, 768, 16          # batch * dim = 98304 rows: the dispatcher's threshold for this kernel
+    B, D, N = (128, 768, 16) if L < 1024 else (48, 768, 16)
     inp = scan_inputs(B, D, L, N, seed=L)
     t = {k: v.to(device) for k, v in inp.items()}
     for k in ("u", "delta", "z", "B", "C", "dout"):
         t[k] = t[k].to(dtype)
     leaves = {k: t[k].clone().requires_grad_(True) for k in ("u", "delta", "z")}
-    out, last = selective_scan_fn(leaves["u"], leaves["delta"], t["A"], t["B"], t["C"], t["D"], leaves["z"],
-                                  t["delta_bias"], True, True)
-    out.backward(t["dout"])
+    with _lib.scan_variant({0: _lib.SCAN_AUTO, 2: _lib.SCAN_LPC2, 4: _lib.SCAN_LPC4}[split]):
+        out, last = selective_scan_fn(leaves["u"], leaves["delta"], t["A"], t["B"], t["C"], t["D"], leaves["z"],
+                                      t["delta_bias"], True, True)
+        # every variant computes the same function: the row-scan kernel agrees to rounding on the whole tensor
+        with torch.no_grad(), _lib.scan_variant(_lib.SCAN_ROWSCAN):
+            out_r, last_r = selective_scan_fn(t["u"], t["delta"], t["A"], t["B"], t["C"], t["D"], t["z"],
+                                              t["delta_bias"], True, True)
     tol = TOL[dtype]
+    assert nerr(out, out_r) < tol and nerr(last, last_r) < tol
+    out.backward(t["dout"])
     g = torch.Generator().manual_seed(1)
     ds = torch.randperm(D, generator=g)[:40]
-    for bi in (0, 77, 127):
+    for bi in (0, B // 2 + 13, B - 1):
         sub = {k: t[k][bi:bi + 1, ds].float().cpu().clone().requires_grad_(True) for k in ("u", "delta", "z")}
         want, wlast = scan_ref.selective_scan_ref(sub["u"], sub["delta"], t["A"][ds].cpu(),
                                                   t["B"][bi:bi + 1].float().cpu(), t["C"][bi:bi + 1].float().cpu(),
@@ -273,6 +277,47 @@ def test_scan_seq_kernel_path(L, dtype, split, device, monkeypatch):
         assert nerr(last[bi:bi + 1, ds], wlast) < tol
         for k in ("u", "delta", "z"):
             assert nerr(leaves[k].grad[bi:bi + 1, ds], sub[k].grad) < tol, k
+
+
+@pytest.mark.parametrize("variant", [2, 4])
+@pytest.mark.parametrize("layout", ["token_major", "odd_strides", "ragged_dim"])
+def test_scan_seq_kernel_operand_layouts(variant, layout, device):
+    """The lanes-per-channel kernel's two B / C staging routes (16-byte packs along time and along the state), strides
+    that keep no pack aligned, a z read through a batch stride, and a channel count that is not a multiple of a
+    wave's channels: bit-for-bit what the same kernel gives on contiguous copies."""
+    from si_mamba_amd import _lib, selective_scan_fn
+    b, d, L, N = 3, (100 if layout == "ragged_dim" else 96), 160, 16
+    inp = scan_inputs(b, d, L, N, seed=77)
+    t = {k: v.to(device) for k, v in inp.items()}
+    if layout == "token_major":            # the mixer's layout: B | C inside the (B, L, R + 2N) x_proj output
+        x_dbl = torch.randn(b, L, 24 + 32, device=device)
+        x_dbl[:, :, 24:40] = t["B"].transpose(1, 2)
+        x_dbl[:, :, 40:] = t["C"].transpose(1, 2)
+        Bs, Cs = x_dbl[:, :, 24:40].transpose(1, 2), x_dbl[:, :, 40:].transpose(1, 2)
+    elif layout == "odd_strides":          # time stride 1 but a state stride of L + 1: no 16-byte pack stays aligned
+        pad = torch.randn(2, b, N, L + 1, device=device)
+        pad[0, :, :, :L], pad[1, :, :, :L] = t["B"], t["C"]
+        Bs, Cs = pad[0, :, :, :L], pad[1, :, :, :L]
+    else:
+        Bs, Cs = t["B"], t["C"]
+    xz = torch.randn(b, 2 * d, L, device=device)
+    xz[:, d:] = t["z"]
+    zs = xz[:, d:]
+    assert not zs.is_contiguous()
+    if layout == "odd_strides":
+        # no aligned pack of B / C exists: an explicit request is refused by name, the library's own choice
+        # (variant AUTO) serves the operands through the row-scan kernel's element-wise gather
+        with torch.no_grad(), _lib.scan_variant(variant), pytest.raises(RuntimeError, match="variant"):
+            selective_scan_fn(t["u"], t["delta"], t["A"], Bs, Cs, t["D"], zs, t["delta_bias"], True, True)
+        variant = _lib.SCAN_AUTO
+    with torch.no_grad(), _lib.scan_variant(variant):
+        got, glast = selective_scan_fn(t["u"], t["delta"], t["A"], Bs, Cs, t["D"], zs, t["delta_bias"], True, True)
+        want, wlast = selective_scan_fn(t["u"], t["delta"], t["A"], t["B"], t["C"], t["D"], t["z"], t["delta_bias"],
+                                        True, True)
+    assert torch.equal(got, want) and torch.equal(glast, wlast)
+    ref = scan_ref.selective_scan_ref(inp["u"][:1], inp["delta"][:1], inp["A"], inp["B"][:1], inp["C"][:1], inp["D"],
+                                      inp["z"][:1], inp["delta_bias"], True)
+    assert nerr(got[:1], ref) < 1e-3
 
 
 def test_scan_strided_operands(device):
@@ -312,7 +357,7 @@ def test_scan_backward_writes_nothing_outside_its_accumulators(device):
     rc = lib.simamba_selective_scan_fwd(_lib.ptr(t["u"]), _lib.ptr(t["delta"]), _lib.ptr(t["A"]), _lib.ptr(t["B"]),
                                         _lib.ptr(t["C"]), _lib.ptr(t["D"]), _lib.ptr(t["z"]),
                                         _lib.ptr(t["delta_bias"]), _lib.ptr(out), None, None, b, d, L, N, 0, 1,
-                                        0, 0, 0, 0, None, 0, st)
+                                        0, 0, 0, 0, 0, st)
     assert rc == 0
 
     def bwd(acc):

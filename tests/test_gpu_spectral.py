@@ -240,3 +240,52 @@ def test_spectral_order_from_centres_matches_golden_order(name, device):
         hit += h
         tot += n
     assert hit / tot > 0.97, (hit, tot)
+
+
+def test_bind_to_patches_reference_style_class(device):
+    """spectral.bind_to: the drop-in route for the reference's PointMamba methods.  A stand-in
+    class with the six method names is patched and every method is called with the reference's own call forms
+    (models/point_mamba.py:620, :664, :717, :764, :817, :829; call sites :872, :884, :889-890, :1056-1060, :3097)."""
+    from si_mamba_amd import spectral
+
+    class RefStyle:                       # carries the attribute the reference tests at :647
+        alpha = 0.0
+
+        def create_graph_from_centers(self, *a, **k): raise AssertionError("not patched")
+        def create_graph_from_feature_space_gpu_weighted_adjacency(self, *a, **k): raise AssertionError("not patched")
+        def calc_top_k_eigenvalues_eigenvectors(self, *a, **k): raise AssertionError("not patched")
+        def calc_top_k_eigenvalues_eigenvectors_symmetric(self, *a, **k): raise AssertionError("not patched")
+        def sort_points_by_fiedler(self, *a, **k): raise AssertionError("not patched")
+        def multilevel_travers(self, *a, **k): raise AssertionError("not patched")
+
+    assert spectral.bind_to(RefStyle) is RefStyle
+    m = RefStyle()
+    g = load_golden("spectral_g64")
+    c = torch.from_numpy(g["centers"]).to(device)
+    cb = SPECTRAL_COMBOS[0]
+    # :872 -- positional, as the reference calls it
+    adj = m.create_graph_from_feature_space_gpu_weighted_adjacency(c, cb["knn"], cb["alpha"], cb["symmetric"],
+                                                                   cb["self_loop"], cb["binary"])
+    np.testing.assert_array_equal(adj.cpu().numpy() != 0, g["hardest.adj"] != 0)
+    # :3097 / :1056 -- the module attribute alpha == 0 selects the sigma = mean-distance weighting (:647)
+    adj0 = m.create_graph_from_centers(c, 10, 0.0, True, True, False)
+    np.testing.assert_allclose(adj0.cpu().numpy(), g["sigma_mean.adj"], rtol=2e-6, atol=0)
+    m.alpha = 10.0
+    adj1 = m.create_graph_from_centers(c, cb["knn"], cb["alpha"], cb["symmetric"], cb["self_loop"], cb["binary"])
+    want1 = sr.create_graph_from_centers(c.cpu(), cb["knn"], cb["alpha"], cb["symmetric"], cb["self_loop"], cb["binary"],
+                                         self_alpha=10.0)
+    np.testing.assert_array_equal(adj1.cpu().numpy() != 0, want1.numpy() != 0)
+    # :884 -- keyword form, 4-tuple result
+    vals, vecs, all_vals, all_vecs = m.calc_top_k_eigenvalues_eigenvectors(adj, k=4, smallest=True)
+    assert vals.shape == (c.shape[0], 4) and vecs.shape == (c.shape[0], 64, 4)
+    assert all_vals.shape == (c.shape[0], 64) and all_vecs.shape == (c.shape[0], 64, 64)
+    np.testing.assert_allclose(vals.cpu().numpy(), g["hardest.vals"], atol=2e-5)
+    v2 = m.calc_top_k_eigenvalues_eigenvectors_symmetric(adj, k=4, smallest=True)[0]
+    np.testing.assert_allclose(v2.cpu().numpy(), g["hardest.sym.vals"], atol=2e-5)
+    # :889-890
+    tokens = torch.randn(c.shape[0], 64, 384, device=device)
+    out = m.sort_points_by_fiedler(tokens, vecs[:, :, 1])
+    assert torch.equal(out.cpu(), sr.sort_points_by_fiedler(tokens.cpu(), vecs[:, :, 1].cpu()))
+    # :1059
+    codes = m.multilevel_travers(vecs, 4)
+    assert torch.equal(codes.cpu(), sr.multilevel_travers(vecs.cpu(), 4))
