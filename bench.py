@@ -159,9 +159,9 @@ def main():
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
     _lib.load()
-    # fp32 library GEMMs take the solutions recorded for this step's shapes (si_mamba_amd/gemm_tuning.py);
-    # look-up only, nothing is tuned inside the run
-    tuned = (not args.no_tuned_gemm) and args.dtype == "f32" and enable_tuned_gemms()
+    # library GEMMs take the solutions recorded for this step's shapes (si_mamba_amd/gemm_tuning.py: every fp32 GEMM
+    # of the step, and the plain -- not strided-batched -- bf16 ones); look-up only, nothing is tuned inside the run
+    tuned = (not args.no_tuned_gemm) and enable_tuned_gemms()
 
     torch.manual_seed(0)                                    # same init on every rank
     cfg = default_config(num_group=args.groups)             # cfgs/finetune_scan_hardest.yaml model block

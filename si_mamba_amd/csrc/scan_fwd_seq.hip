@@ -30,7 +30,12 @@
 namespace simamba {
 
 constexpr int kSeqTC = 32;                 // timesteps per chunk: one 128-byte line of an fp32 row
-constexpr int kSeqThreads = 256;           // 4 independent waves
+#ifndef SIMAMBA_SEQ_WAVES
+#define SIMAMBA_SEQ_WAVES 1
+#endif
+// The waves never synchronise with each other, so a workgroup is ONE wave: the dispatcher then balances at wave
+// granularity (with 4-wave workgroups a grid of 384 workgroups put 8 waves on half of the CUs and 4 on the rest).
+constexpr int kSeqThreads = 64 * SIMAMBA_SEQ_WAVES;
 constexpr int kBcPitch = 36;               // floats per staged B_t | C_t row (32 + 4)
 
 struct SeqArgs {
@@ -264,6 +269,13 @@ __global__ __launch_bounds__(kSeqThreads, SeqCfg<kLPC>::kWaves) void scan_fwd_se
       const float4 u4 = *reinterpret_cast<const float4*>(tU + o);
       const float dl[4] = {d4.x, d4.y, d4.z, d4.w};
       const float uu[4] = {u4.x, u4.y, u4.z, u4.w};
+      // z of this chunk is requested half way through the recurrence: early enough that its HBM latency is over
+      // by phase C even when this wave is alone on its SIMD, late enough that its registers are free before
+      if (kHasZ && g == kSeqTC / 8) {
+#pragma unroll
+        for (int j = 0; j < kPacks; ++j)
+          load4<T>(zg, rowoff[j] + zdelta + (in_seq ? t0 * kEsz : 0u - 4u * qv * kEsz), zv[j]);
+      }
       float yy[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -305,12 +317,8 @@ __global__ __launch_bounds__(kSeqThreads, SeqCfg<kLPC>::kWaves) void scan_fwd_se
       // next to DPP code)
       *reinterpret_cast<float4*>(tU + o) = make_float4(yy[0], yy[1], yy[2], yy[3]);
     }
-    // z of this chunk and B | C of the next: requested only now so that their registers are free during the
-    // recurrence; the latency hides under phase C and the other resident waves
-    if (kHasZ) {
-#pragma unroll
-      for (int j = 0; j < kPacks; ++j) load4<T>(zg, rowoff[j] + zdelta + (in_seq ? t0 * kEsz : 0u - 4u * qv * kEsz), zv[j]);
-    }
+    // B | C of the next chunk: requested only now so that their registers are free during the recurrence; the
+    // latency hides under phase C and phase A
     if (c + 1 < nchunks) issue_bc(t0 + kSeqTC);
     // state checkpoints at the 128-step boundaries the backward uses, and the final state
     const int tend = t0 + kSeqTC;

@@ -6,7 +6,9 @@ a GEMM shape and remember the winner; ``si_mamba_amd/tuned/gemm_gfx950.csv`` hol
 the benchmark configurations (made once on an MI355X by tools/tune_gemm.py; the file carries the library
 versions it is valid for and PyTorch ignores it when they differ).  ``enable_tuned_gemms()`` switches TunableOp on
 in read-only mode: listed shapes take the recorded solution, every other shape the library default; nothing is
-timed or written at run time.  Measured on the bench step: 67.9 -> 62.5 ms (fp32, B=64).
+timed or written at run time.  Measured on the bench step: 67.9 -> 62.5 ms (fp32, B=64).  bf16 (autocast): only the
+plain GEMMs are listed; the library's candidate sweep for bf16 STRIDED-BATCHED GEMMs faults the GPU on dense operands
+(tools/tune_gemm_offline.py, profiles/r02c_bf16_tune_fault*.log), so the mixer's bf16 projections keep the default.
 """
 from __future__ import annotations
 
