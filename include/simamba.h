@@ -12,6 +12,8 @@
  *                                    at models/point_mamba.py:162.
  *   simamba_causal_conv1d_fwd/bwd    causal_conv1d_cuda.causal_conv1d_fwd/bwd of causal-conv1d,
  *                                    same call site (inside the mixer).
+ *   simamba_xdt_proj_fwd             the x_proj / dt_proj GEMM pair of the same mixer (cuBLAS calls inside
+ *                                    upstream's mamba_inner_fn).
  *   simamba_add_layer_norm_fwd/bwd   the Add -> LayerNorm of models/block.py:56-60 (torch ops there).
  *   simamba_knn_graph                models/point_mamba.py:620-661 and :664-715
  *                                    (create_graph_from_centers / ..._feature_space_...).
@@ -117,6 +119,19 @@ int simamba_selective_scan_bwd(const void* u, const void* delta, const float* A,
                                int io_dtype, int delta_softplus, long long z_bstride,
                                long long dz_bstride, long long bc_bstride, long long bc_nstride,
                                long long bc_tstride, void* stream);
+
+/*
+ * Fused x_proj -> dt_proj of the mixer on the matrix cores (the two skinny GEMMs between the conv and the scan
+ * inside upstream's mamba_inner_fn, reached from models/block.py:72):
+ *   xdbl[b, t, s]  = sum_d wx[s, d] * x[b, d, t]            (batch, seqlen, S) token-major, S = dt_rank + 2 * dstate
+ *   delta[b, d, t] = sum_r wdt[d, r] * xdbl[b, t, r], r < R (batch, D, seqlen)
+ *   x : (batch, D, seqlen), seqlen contiguous, batch stride x_bstride elements (0 => D * seqlen);
+ *   wx : (S, D) fp32 ; wdt : (D, R) fp32.  SIMAMBA_F32 only (exact fp32 MFMA, v_mfma_f32_32x32x2_f32);
+ *   D % 32 == 0, seqlen % 4 == 0, S % 4 == 0, S <= 64, R % 4 == 0, 4 <= R <= 24, 16-byte aligned pointers.
+ */
+int simamba_xdt_proj_fwd(const void* x, const float* wx, const float* wdt, void* xdbl, void* delta,
+                         int batch, int D, int seqlen, int S, int R, int io_dtype, long long x_bstride,
+                         void* stream);
 
 /*
  * Causal depthwise conv1d (+ optional SiLU).

@@ -11,7 +11,8 @@ ops it never copies an activation-sized tensor:
   * every GEMM is issued in the orientation that yields an L-contiguous ``(B, *, L)`` result, so no
     transposition kernel runs.
 
-The four projections stay library GEMMs (hipBLASLt through torch.matmul / baddbmm).
+in_proj, out_proj and every backward product are library GEMMs (hipBLASLt / rocBLAS through torch.bmm); the skinny
+x_proj -> dt_proj pair of the fp32 forward is one hand-written MFMA kernel (csrc/xdt_proj.hip).
 """
 from __future__ import annotations
 
@@ -77,6 +78,33 @@ def in_proj_fn(hidden, weight, bias=None):
     return InProjFn.apply(hidden, weight, bias)
 
 
+def xdt_proj_fused_ok(x, wx, wdt):
+    """Shapes / dtypes the hand-written MFMA kernel takes (include/simamba.h); anything else runs the two library
+    GEMMs."""
+    S, D = wx.shape
+    R = wdt.shape[1]
+    return (x.is_cuda and x.dtype == torch.float32 and wx.dtype == torch.float32 and wdt.dtype == torch.float32
+            and x.dim() == 3 and x.stride(2) == 1 and x.stride(1) == x.shape[2] and x.stride(0) % 4 == 0
+            and x.shape[1] == D and D % 32 == 0 and x.shape[2] % 4 == 0 and S % 4 == 0 and S <= 64
+            and R % 4 == 0 and 4 <= R <= 24 and S >= R and wdt.shape[0] == D and x.data_ptr() % 16 == 0)
+
+
+def xdt_proj_fwd(x, wx, wdt):
+    """x (B, D, L) fp32, wx (S, D), wdt (D, R) -> x_dbl (B, L, S) token-major, delta (B, D, L).  No autograd: called
+    from inside MambaInnerFn.forward, whose backward differentiates the two products itself."""
+    lib = _lib.load()
+    Bsz, D, L = x.shape
+    S, R = wx.shape[0], wdt.shape[1]
+    wxc, wdc = wx.contiguous(), wdt.contiguous()
+    x_dbl = torch.empty(Bsz, L, S, device=x.device, dtype=x.dtype)
+    delta = torch.empty(Bsz, D, L, device=x.device, dtype=x.dtype)
+    with torch.cuda.device(x.device), _lib.timed("xdt_proj_fwd", x.device):
+        rc = lib.simamba_xdt_proj_fwd(x.data_ptr(), wxc.data_ptr(), wdc.data_ptr(), x_dbl.data_ptr(), delta.data_ptr(),
+                                      Bsz, D, L, S, R, _lib.F32, x.stride(0), _lib.stream_ptr(x.device))
+    _lib.check(rc, "simamba_xdt_proj_fwd")
+    return x_dbl, delta
+
+
 class MambaInnerFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, xz, conv_w, conv_b, x_proj_w, dt_proj_w, out_proj_w, out_proj_b, A, D, delta_bias,
@@ -111,8 +139,12 @@ class MambaInnerFn(torch.autograd.Function):
 
         xw_c, dtw_c, ow_c = _w(x_proj_w, io), _w(dt_proj_w, io), _w(out_proj_w, io)   # compute-dtype weights,
         ctx.wcast = (xw_c, dtw_c, ow_c)                                               # reused by backward
-        x_dbl = _xw(x_conv.transpose(1, 2), xw_c.t())                                  # (B, L, S)
-        delta = _wx(dtw_c, x_dbl[:, :, :R].transpose(1, 2))                            # (B, D, L)
+        if xdt_proj_fused_ok(x_conv, xw_c, dtw_c):
+            # x_proj -> dt_proj as ONE pass over x_conv on the matrix cores (csrc/xdt_proj.hip)
+            x_dbl, delta = xdt_proj_fwd(x_conv, xw_c, dtw_c)
+        else:
+            x_dbl = _xw(x_conv.transpose(1, 2), xw_c.t())                              # (B, L, S)
+            delta = _wx(dtw_c, x_dbl[:, :, :R].transpose(1, 2))                        # (B, D, L)
         Bv, Cv = x_dbl[:, :, R:R + N], x_dbl[:, :, R + N:]                            # (B, L, N) views
 
         nchunks = lib.simamba_scan_num_chunks(L)

@@ -1,0 +1,70 @@
+"""GPU parity of the fused x_proj -> dt_proj MFMA kernel (csrc/xdt_proj.hip) through the C ABI:
+against the oracle's two matrix products in float64 (the kernel is an exact-fp32 MFMA chain: 1e-3 is the
+north-star bar, the observed error is at the fp32 rounding level), and against the library-GEMM route of the mixer."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def nerr(got, want):
+    got, want = got.detach().double().cpu(), want.detach().double().cpu()
+    return ((got - want).abs().max() / max(1.0, want.abs().max().item())).item()
+
+
+@pytest.mark.parametrize("B,D,L,N,R", [(2, 768, 1024, 16, 24), (3, 256, 64, 16, 8), (1, 768, 208, 16, 24),
+                                       (2, 128, 36, 16, 8), (64, 768, 1024, 16, 24), (1, 64, 4, 16, 4)])
+def test_xdt_proj_matches_float64_products(B, D, L, N, R, device):
+    from si_mamba_amd.mamba_inner import xdt_proj_fused_ok, xdt_proj_fwd
+    S = R + 2 * N
+    g = torch.Generator().manual_seed(D + L)
+    x = torch.randn(B, D, L, generator=g)
+    wx = torch.randn(S, D, generator=g) / D ** 0.5
+    wdt = torch.randn(D, R, generator=g) / R ** 0.5
+    xd, wxd, wdd = x.to(device), wx.to(device), wdt.to(device)
+    assert xdt_proj_fused_ok(xd, wxd, wdd)
+    x_dbl, delta = xdt_proj_fwd(xd, wxd, wdd)
+    sel = slice(None) if B <= 3 else torch.tensor([0, B // 2, B - 1])          # float64 oracle on a few samples
+    want_dbl = torch.einsum("sd,bdt->bts", wx.double(), x[sel].double())
+    want_delta = torch.einsum("dr,btr->bdt", wdt.double(), want_dbl[:, :, :R])
+    assert nerr(x_dbl[sel], want_dbl) < 1e-5
+    assert nerr(delta[sel], want_delta) < 1e-5
+    # and bit-for-bit deterministic
+    x_dbl2, delta2 = xdt_proj_fwd(xd, wxd, wdd)
+    assert torch.equal(x_dbl, x_dbl2) and torch.equal(delta, delta2)
+
+
+def test_xdt_proj_reads_a_batch_strided_input(device):
+    from si_mamba_amd.mamba_inner import xdt_proj_fwd
+    g = torch.Generator().manual_seed(3)
+    big = torch.randn(3, 2 * 256, 128, generator=g).to(device)
+    x = big[:, :256]                                                           # half of an in_proj-style (B, 2D, L)
+    wx, wdt = torch.randn(40, 256, generator=g).to(device), torch.randn(256, 8, generator=g).to(device)
+    a = xdt_proj_fwd(x, wx, wdt)
+    b = xdt_proj_fwd(x.contiguous(), wx, wdt)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+def test_mixer_uses_the_fused_kernel_and_matches_the_library_route(device, monkeypatch):
+    """The fp32 mixer forward with the fused kernel against the same mixer forced onto the two library GEMMs:
+    outputs and every gradient (the backward is shared) agree at the fp32 rounding level."""
+    from si_mamba_amd import Mamba, mamba_inner
+    torch.manual_seed(0)
+    m = Mamba(384).to(device)
+    h = torch.randn(2, 256, 384, device=device)
+    calls = []
+    real = mamba_inner.xdt_proj_fwd
+    monkeypatch.setattr(mamba_inner, "xdt_proj_fwd", lambda *a: (calls.append(1), real(*a))[1])
+    h1 = h.clone().requires_grad_(True)
+    o1 = m(h1)
+    o1.sum().backward()
+    g1 = {k: p.grad.clone() for k, p in m.named_parameters()}
+    assert calls, "fp32 mixer forward did not take the fused x_proj -> dt_proj kernel"
+    m.zero_grad(set_to_none=True)
+    monkeypatch.setattr(mamba_inner, "xdt_proj_fused_ok", lambda *a: False)
+    h2 = h.clone().requires_grad_(True)
+    o2 = m(h2)
+    o2.sum().backward()
+    assert nerr(o1, o2) < 1e-5 and nerr(h1.grad, h2.grad) < 1e-5
+    for k, p in m.named_parameters():
+        assert nerr(g1[k], p.grad) < 1e-4, k
