@@ -134,6 +134,20 @@ int simamba_xdt_proj_fwd(const void* x, const float* wx, const float* wdt, void*
                          void* stream);
 
 /*
+ * Token-sequence expansion along the last axis and its adjoint.  The reference's block stack sees L = 2 k G tokens
+ * that are the same G patch tokens in 2 k orders (models/point_mamba.py:889-898, :982-989); the per-token head of the
+ * first block (Add, LayerNorm, in_proj: models/block.py:56-60) is computed on the G distinct tokens and expanded:
+ *   fwd: out[b, c, l] = in[b, c, idx[b, l]]              in (batch, channels, G), idx (batch, L) int32,
+ *                                                        out (batch, channels, L) with batch stride out_bstride
+ *   bwd: din[b, c, g] = sum_j dout[b, c, inv[b, g, j]]   inv (batch, G, R) int32: the R = L / G positions of token g
+ *   G <= 256, L <= 2048, G % 4 == 0, L % 4 == 0, R <= 8; idx 16-byte aligned.  Deterministic (no atomics).
+ */
+int simamba_seq_gather_fwd(const void* in, const int* idx, void* out, int batch, int channels, int G, int L,
+                           long long out_bstride, int io_dtype, void* stream);
+int simamba_seq_gather_bwd(const void* dout, const int* inv, void* din, int batch, int channels, int G, int L,
+                           int R, long long dout_bstride, int io_dtype, void* stream);
+
+/*
  * Causal depthwise conv1d (+ optional SiLU).
  *   x, out, dout, dx : (batch, dim, seqlen) io_dtype
  *   w : (dim, width) fp32; bias : (dim) fp32 or NULL; dw, dbias fp32, zeroed then accumulated.

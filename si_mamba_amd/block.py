@@ -135,10 +135,52 @@ class MixerModel(nn.Module):
         return {i: layer.allocate_inference_cache(batch_size, max_seqlen, dtype=dtype, **kwargs)
                 for i, layer in enumerate(self.layers)}
 
-    def forward(self, input_ids, pos, inference_params=None):
-        hidden_states = input_ids + pos
+    def _first_block_on_distinct_tokens(self, tokens, pos, token_index):
+        """Block 0 when the sequence is ``gather(tokens + pos, token_index)``: Add + LayerNorm + in_proj on the G
+        distinct tokens, expanded to the L positions by a copy kernel (seq_expand.py).  -> (hidden, residual) of
+        block 0 as the reference's Block.forward returns them, or None when the route does not apply."""
+        from . import seq_expand
+        layer = self.layers[0]
+        mixer = layer.mixer
+        if not (tokens.is_cuda and type(layer.norm) is nn.LayerNorm and isinstance(mixer, Mamba)
+                and mixer.use_fast_path and seq_expand.expansion_ok(tokens, token_index)):
+            return None
+        inv32 = seq_expand.inverse_positions(token_index, tokens.shape[1])
+        if inv32 is None:
+            return None
+        idx32 = token_index.to(torch.int32).contiguous()
+        # residual_0 = tokens + pos and its LayerNorm in one pass over the G tokens.  (Low-precision operands: the
+        # reference's `input_ids + pos` rounds the sum to that dtype first -- keep that rounding.)
+        if tokens.dtype == torch.float32:
+            normed, res0 = add_layer_norm_fn(tokens, pos, layer.norm.weight, layer.norm.bias, layer.norm.eps)
+        else:
+            normed, res0 = add_layer_norm_fn(tokens + pos, None, layer.norm.weight, layer.norm.bias, layer.norm.eps)
+        xz = seq_expand.seq_gather_last(mixer.in_proj_xz(normed), idx32, inv32)          # (B, 2D, L)
+        hidden = mixer.forward_xz(xz)
+        residual = torch.gather(res0, 1, token_index.unsqueeze(-1).expand(-1, -1, res0.shape[-1]))
+        return hidden, residual
+
+    def forward(self, input_ids, pos, inference_params=None, token_index=None):
+        """Reference signature (models/point_mamba.py:247).  ``token_index`` (B, L) int64, optional and specific to
+        this implementation: when given, ``input_ids`` / ``pos`` are the G DISTINCT tokens (B, G, C) and the sequence
+        the reference would be handed is their gather by ``token_index``; the result is the same, the first block's
+        per-token head runs on G tokens instead of L."""
+        first = 0
         residual = None
-        for layer in self.layers:
+        if token_index is not None:
+            done = (self._first_block_on_distinct_tokens(input_ids, pos, token_index)
+                    if inference_params is None else None)
+            if done is not None:
+                hidden_states, residual = done
+                hidden_states = self.drop_out_in_block(hidden_states)
+                first = 1
+            else:                                       # the reference's route on the expanded sequence
+                ex = token_index.unsqueeze(-1)
+                input_ids = torch.gather(input_ids, 1, ex.expand(-1, -1, input_ids.shape[-1]))
+                pos = torch.gather(pos, 1, ex.expand(-1, -1, pos.shape[-1]))
+        if first == 0:
+            hidden_states = input_ids + pos
+        for layer in self.layers[first:]:
             hidden_states, residual = layer(hidden_states, residual, inference_params=inference_params)
             hidden_states = self.drop_out_in_block(hidden_states)
         if hidden_states.is_cuda and type(self.norm_f) is nn.LayerNorm and hidden_states.dim() == 3:

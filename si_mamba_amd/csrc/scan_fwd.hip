@@ -168,8 +168,12 @@ int scan_fwd_seq_bc_mode(const void* B, const void* C, int io_dtype, long long b
 // kernel (scan_fwd_seq.hip) issues 5 VALU per (row, step, state) against ~7 for the row-scan kernel, but a wave
 // covers 64 / lpc whole rows: it needs rows / (64 / lpc) waves to give every one of the 1024 SIMDs its 3 waves.
 static int auto_variant(long long rows) {
-  if (rows >= 3 * 1024 * 32) return SIMAMBA_SCAN_LPC2;      // >= 98 304 rows: two lanes per channel
-  // below that the row-scan kernel wins: measured at (64,768,1024,16) row-scan 316 us, LPC4 335 us, LPC2 366 us
+  // Two lanes per channel from 49 152 rows on (1.5 waves per SIMD).  Measured kernel times, fp32, rocprofv3 medians:
+  //   (64,768,1024): row-scan 329-334 us, LPC2 307-311 us, LPC4 313-320 us      (49 152 rows)
+  //   (64,768, 512): row-scan 179 us,     LPC2 156 us,     LPC4 152 us
+  //   (32,768,1024): row-scan 182 us,     LPC2 198 us,     LPC4 207 us          (24 576 rows: too few waves)
+  //   (256,768,128): row-scan 165 us,     LPC2 115 us                           (196 608 rows, the north-star shape)
+  if (rows >= 48 * 1024) return SIMAMBA_SCAN_LPC2;
   return SIMAMBA_SCAN_ROWSCAN;
 }
 

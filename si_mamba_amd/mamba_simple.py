@@ -87,12 +87,7 @@ class Mamba(nn.Module):
         A = -torch.exp(self.A_log.float())
         # (2D, d) @ (B, d, L) -> (B, 2D, L): L is the contiguous axis the HIP kernels stream along
         if self.use_fast_path:
-            xz = in_proj_fn(hidden_states, self.in_proj.weight, self.in_proj.bias)
-            # one autograd node, no activation-sized copies (mamba_inner.py)
-            return mamba_inner_fn(xz, self.conv1d.weight, self.conv1d.bias, self.x_proj.weight,
-                                  self.dt_proj.weight, self.out_proj.weight, self.out_proj.bias, A,
-                                  self.D.float(), delta_bias=self.dt_proj.bias.float(),
-                                  dt_rank=self.dt_rank, d_state=self.d_state)
+            return self.forward_xz(self.in_proj_xz(hidden_states))
         # reference composition of the separate ops (same kernels; torch.matmul / chunk copy the views)
         xz = torch.matmul(self.in_proj.weight, hidden_states.transpose(1, 2))
         if self.in_proj.bias is not None:
@@ -108,6 +103,21 @@ class Mamba(nn.Module):
         if self.out_proj.bias is not None:
             out = out + self.out_proj.bias.to(out.dtype)
         return out
+
+    def in_proj_xz(self, hidden_states):
+        """(B, L, d_model) -> xz (B, 2 d_inner, L), L contiguous: the in_proj half of forward()."""
+        return in_proj_fn(hidden_states, self.in_proj.weight, self.in_proj.bias)
+
+    def forward_xz(self, xz):
+        """xz (B, 2 d_inner, L) -> (B, L, d_model): everything after in_proj as one autograd node, no
+        activation-sized copies (mamba_inner.py).  forward(h) == forward_xz(in_proj_xz(h)); MixerModel calls the two
+        halves separately for the first block when the sequence is an expansion of fewer distinct tokens
+        (seq_expand.py)."""
+        A = -torch.exp(self.A_log.float())
+        return mamba_inner_fn(xz, self.conv1d.weight, self.conv1d.bias, self.x_proj.weight,
+                              self.dt_proj.weight, self.out_proj.weight, self.out_proj.bias, A,
+                              self.D.float(), delta_bias=self.dt_proj.bias.float(),
+                              dt_rank=self.dt_rank, d_state=self.d_state)
 
     def allocate_inference_cache(self, batch_size, max_seqlen, dtype=None, **kwargs):
         raise NotImplementedError("inference caches are outside the SI-Mamba hot path")

@@ -176,6 +176,17 @@ class PointMamba(nn.Module):
     def spectral_order(self, center):
         return self.spectral_eigs(center)[2]
 
+    def token_index(self, center, order=None):
+        """(B, L) int64 patch index of every sequence position for the routes that are pure gathers (SAST :868-989,
+        MAMBA :850-866); None for HLT, whose assembly also writes zeros (:1075-1112)."""
+        if self.method == "SAST":
+            if order is None:
+                order = self.spectral_order(center)
+            return spectral.sast_index_map(order, self.reverse)
+        if self.method == "MAMBA":
+            return torch.cat([center[:, :, a].argsort(dim=-1) for a in range(3)], dim=1)
+        return None
+
     def order_tokens(self, tokens, pos, center, order=None):
         """Tokens and positions in sequence order for ``self.method`` (reference :850-1112)."""
         if self.method == "SAST":                                               # :868-989
@@ -232,9 +243,15 @@ class PointMamba(nn.Module):
             main.wait_stream(side)
             for t in spec:
                 t.record_stream(main)
-        x, pos = self.order_tokens(tokens, pos, center, order)
-        x = self.drop_out(x)
-        x = self.blocks(x, pos)
+        idx = self.token_index(center, order)
+        if idx is not None and not (self.training and self.drop_out.p > 0):
+            # the sequence is a gather of the G patch tokens: the stack takes the distinct tokens plus the index map
+            # and runs the first block's per-token head on G instead of L positions (seq_expand.py); same result
+            x = self.blocks(tokens, pos, token_index=idx)
+        else:
+            x, pos = self.order_tokens(tokens, pos, center, order)
+            x = self.drop_out(x)
+            x = self.blocks(x, pos)
         x = self.norm(x)
         ret = self.cls_head_finetune(x.mean(1))
         if not want_policy:

@@ -354,3 +354,68 @@ def test_pointmamba_reference_call_surface(device):
         m(pts, gt=None, tau=None, use_wavelets=True)
     with pytest.raises(NotImplementedError, match="tau"):
         m(pts, tau=0.5)
+
+
+def test_first_block_on_distinct_tokens_equals_reference_route(device):
+    """MixerModel.forward(tokens, pos, token_index=idx) -- Add + LayerNorm + in_proj of block 0 on the G distinct tokens,
+    expanded by the copy kernels of csrc/seq_gather.hip -- against the reference's route on the gathered sequence
+    (models/point_mamba.py:889-898, :982-989 then :247-258): outputs, input gradients and every parameter gradient."""
+    import copy
+    from si_mamba_amd.block import MixerModel
+    from compose import nerr
+    torch.manual_seed(0)
+    a = MixerModel(d_model=128, n_layer=2, drop_path=0.).to(device)
+    b = copy.deepcopy(a)
+    B, G, k = 3, 64, 4
+    g = torch.Generator().manual_seed(1)
+    tokens, pos = torch.randn(B, G, 128, generator=g).to(device), torch.randn(B, G, 128, generator=g).to(device)
+    order = torch.stack([torch.stack([torch.randperm(G, generator=g) for _ in range(k)]) for _ in range(B)]).to(device)
+    idx = torch.cat((order.flatten(1), order.flatten(1).flip(1)), 1)                      # (B, 2 k G)
+    calls = []
+    from si_mamba_amd import seq_expand
+    real = seq_expand.seq_gather_last
+    seq_expand.seq_gather_last = lambda *x: (calls.append(1), real(*x))[1]
+    try:
+        ta, pa = tokens.clone().requires_grad_(True), pos.clone().requires_grad_(True)
+        oa = a(ta, pa, token_index=idx)
+    finally:
+        seq_expand.seq_gather_last = real
+    assert calls, "the distinct-token route was not taken"
+    tb, pb = tokens.clone().requires_grad_(True), pos.clone().requires_grad_(True)
+    ex = idx.unsqueeze(-1).expand(-1, -1, 128)
+    ob = b(torch.gather(tb, 1, ex), torch.gather(pb, 1, ex))
+    w = torch.randn(oa.shape, generator=g).to(device)
+    (oa * w).sum().backward()
+    (ob * w).sum().backward()
+    assert nerr(oa, ob) < 1e-5
+    assert nerr(ta.grad, tb.grad) < 1e-4 and nerr(pa.grad, pb.grad) < 1e-4
+    for (ka, qa), (_, qb) in zip(a.named_parameters(), b.named_parameters()):
+        assert nerr(qa.grad, qb.grad) < 1e-4, ka
+    # an index in which the tokens do not occur equally often falls back to the reference's route
+    idx2 = idx.clone()
+    idx2[:, 0] = idx2[:, 1]
+    with torch.no_grad():
+        o2 = a(tokens, pos, token_index=idx2)
+        ex2 = idx2.unsqueeze(-1).expand(-1, -1, 128)
+        assert nerr(o2, b(torch.gather(tokens, 1, ex2), torch.gather(pos, 1, ex2))) < 1e-5
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,C,G,R", [(3, 40, 128, 8), (2, 1536, 64, 8), (1, 5, 256, 8), (2, 16, 32, 4)])
+def test_seq_gather_kernels(B, C, G, R, dtype, device):
+    from si_mamba_amd import seq_expand
+    g = torch.Generator().manual_seed(G + C)
+    L = G * R
+    x = torch.randn(B, C, G, generator=g).to(device).to(dtype).requires_grad_(True)
+    idx = torch.stack([torch.cat([torch.randperm(G, generator=g) for _ in range(R)]) for _ in range(B)]).to(device)
+    inv = seq_expand.inverse_positions(idx, G)
+    assert torch.equal(torch.gather(idx, 1, inv.flatten(1).long()).view(B, G, R),
+                       torch.arange(G, device=device)[None, :, None].expand(B, G, R))
+    out = seq_expand.seq_gather_last(x, idx.to(torch.int32), inv)
+    want = torch.gather(x.detach(), 2, idx.unsqueeze(1).expand(-1, C, -1))
+    assert torch.equal(out, want)                                                   # a copy: bit-exact
+    dout = torch.randn(B, C, L, generator=g).to(device).to(dtype)
+    out.backward(dout)
+    wgrad = torch.zeros(B, C, G, device=device, dtype=torch.float32).scatter_add_(
+        2, idx.unsqueeze(1).expand(-1, C, -1), dout.float())
+    assert (x.grad.float() - wgrad).abs().max() < (1e-5 if dtype == torch.float32 else 6e-2) * max(1.0, wgrad.abs().max().item())

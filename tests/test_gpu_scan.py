@@ -239,11 +239,11 @@ def test_scan_backward_full_size_reductions(shape, dtype, device):
     assert torch.isfinite(nrm).all() and (nrm > 0.25 * nrm[bs].min()).all() and (nrm < 4 * nrm[bs].max()).all()
 
 
-# ---- the lanes-per-channel forward (the library's choice from 32 768 rows on; forced here through the ABI's variant) --
+# ---- the lanes-per-channel forward (the library's choice from 49 152 rows on; forced here through the ABI's variant) --
 @pytest.mark.parametrize("L,dtype,split", [(16, torch.float32, 2), (40, torch.float32, 4), (132, torch.float32, 2),
                                            (260, torch.float32, 4), (260, torch.float32, 2), (32, torch.float32, 2),
                                            (128, torch.float32, 0), (136, torch.bfloat16, 2),
-                                           (264, torch.bfloat16, 4), (1024, torch.float32, 4)])
+                                           (264, torch.bfloat16, 4), (1024, torch.float32, 4), (1024, torch.float32, 2)])
 def test_scan_seq_kernel_path(L, dtype, split, device):
     """Same parity bar as the row-scan kernel, on a row subset (the full tensor is too slow for the CPU
     oracle), including the chunk checkpoints it hands to the backward (L > 128) and the final state.
