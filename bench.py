@@ -87,8 +87,13 @@ def cpu_baseline(npts, groups, seed=0):
 
 
 def headline_scan(device, iters=30):
-    """North-star micro-shape: scan fwd (and bwd) at (B,D,L,N) = (256,768,128,16), fp32."""
-    from si_mamba_amd import selective_scan_fn
+    """North-star micro-shape: scan fwd (and bwd) at (B,D,L,N) = (256,768,128,16), fp32.
+
+    Two clocks per direction: ``ms`` brackets ONE call of the Python op with events (what round 1 reported: it
+    includes the ~25 us launch gap of an idle stream), ``kernel_ms`` divides an event-bracketed train of
+    back-to-back raw C-ABI launches by their number -- the kernel's own duration plus the ~1.5 us boundary, the
+    figure rocprofv3 --kernel-trace reports (profiles/)."""
+    from si_mamba_amd import _lib, selective_scan_fn
     from si_mamba_amd.synthetic import scan_inputs
     B, D, L, N = 256, 768, 128, 16
     t = {k: (v.to(device) if v is not None else None) for k, v in scan_inputs(B, D, L, N, seed=0).items()}
@@ -116,8 +121,45 @@ def headline_scan(device, iters=30):
         nbytes = scan_fwd_bytes(B, D, L, N) if mode == "fwd" else scan_bwd_bytes(B, D, L, N)
         res[mode] = {"ms": round(med, 4), "GB/s": round(nbytes / med / 1e6, 1),
                      "frac_of_8TBs": round(nbytes / med / 1e6 / HBM_PEAK_GBS, 4)}
+    # back-to-back raw launches through the C ABI
+    lib = _lib.load()
+    st = _lib.stream_ptr(device)
+    d = {k: v.detach() for k, v in t.items() if v is not None}
+    out = torch.empty_like(d["u"])
+    du, dd, dz = (torch.empty_like(d["u"]) for _ in range(3))
+    acc = _lib.scan_bwd_accumulators(B, D, L, N, True, True, device)
+
+    def fwd():
+        return lib.simamba_selective_scan_fwd(d["u"].data_ptr(), d["delta"].data_ptr(), d["A"].data_ptr(),
+                                              d["B"].data_ptr(), d["C"].data_ptr(), d["D"].data_ptr(), d["z"].data_ptr(),
+                                              d["delta_bias"].data_ptr(), out.data_ptr(), None, None, B, D, L, N, 0, 1,
+                                              0, 0, 0, 0, 0, st)
+
+    def bwd():
+        return lib.simamba_selective_scan_bwd(d["u"].data_ptr(), d["delta"].data_ptr(), d["A"].data_ptr(),
+                                              d["B"].data_ptr(), d["C"].data_ptr(), d["D"].data_ptr(), d["z"].data_ptr(),
+                                              d["delta_bias"].data_ptr(), d["dout"].data_ptr(), None, du.data_ptr(),
+                                              dd.data_ptr(), acc[0].data_ptr(), acc[1].data_ptr(), acc[2].data_ptr(),
+                                              acc[3].data_ptr(), dz.data_ptr(), acc[4].data_ptr(), B, D, L, N, 0, 1,
+                                              0, 0, 0, 0, 0, st)
+
+    for mode, fn in (("fwd", fwd), ("bwd", bwd)):
+        for _ in range(5):
+            assert fn() == 0
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(iters):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        ms = a.elapsed_time(b) / iters
+        nbytes = scan_fwd_bytes(B, D, L, N) if mode == "fwd" else scan_bwd_bytes(B, D, L, N)
+        res[mode].update({"kernel_ms": round(ms, 4), "kernel_GB/s": round(nbytes / ms / 1e6, 1),
+                          "kernel_frac_of_8TBs": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4)})
     res["shape"] = [B, D, L, N]
-    res["note"] = "event-bracketed C-ABI call; bwd includes its 5 memset nodes"
+    res["note"] = ("ms: one event-bracketed call of the Python op (includes the launch gap of an idle stream); kernel_ms: "
+                   "a train of back-to-back C-ABI launches / their number (kernel + boundary; bwd includes its memset "
+                   "node); fwd kernel: scan_fwd_seq_kernel<float,true,2> (two lanes per channel, 32-step chunks)")
     return res
 
 
@@ -227,14 +269,19 @@ def main():
             n, ms = ktimes["scan_fwd"]
             nbytes = scan_fwd_bytes(args.batch, D, L, N, s)
             ach = nbytes / ms / 1e6
+            rows = args.batch * D
+            fwd_kernel = (f"scan_fwd_seq_kernel<{'float' if s == 4 else 'bf16'},true,2>" if rows >= 48 * 1024 else
+                          f"scan_fwd_kernel<{'float' if s == 4 else 'bf16'},{16 if L >= 768 else 8}>")
             out["roofline"] = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(ach / HBM_PEAK_GBS, 4),
                                "traffic": traffic_from_profiles("scan_fwd", (args.batch, D, L, N)) if s == 4 else None,
-                               "kernel": f"scan_fwd_kernel<{'float' if s == 4 else 'bf16'},{16 if L >= 768 else 8}>",
+                               "kernel": fwd_kernel,
                                "shape_BDLN": [args.batch, D, L, N], "algorithmic_bytes": nbytes,
                                "launches": n, "mean_ms": round(ms, 4),
-                               "note": "exp2/FMA-bound on CDNA4, not HBM-bound: PMC shows the VALU 76-80 % busy at "
-                                       "~2.0 GHz and HBM traffic within 1.1x of algorithmic (DESIGN.md 4.1)"}
+                               "note": "VALU-bound on CDNA4, not HBM-bound (DESIGN.md 4.1): 5 VALU per (row, step, "
+                                       "state) incl. one quarter-rate v_exp_f32 and two DPP operands; PMC: VALU "
+                                       ">90 % busy, HBM traffic 1.0x algorithmic. At this shape 1536 waves on 1024 "
+                                       "SIMDs: half of the SIMDs carry two waves"}
             out["kernels"] = {k: {"launches": v[0], "mean_ms": round(v[1], 4)} for k, v in ktimes.items()}
             if "scan_bwd" in ktimes:
                 bb = scan_bwd_bytes(args.batch, D, L, N, s)
@@ -247,7 +294,8 @@ def main():
                     "traffic": traffic_from_profiles("scan_bwd", (args.batch, D, L, N)) if s == 4 else None,
                     "kernel": f"scan_bwd_kernel<{'float' if s == 4 else 'bf16'},8>", "algorithmic_bytes": bb,
                     "launches": nb, "mean_ms": round(msb, 4),
-                    "note": "VALU-bound (PMC: VALU 68 % busy at 2 waves/SIMD, 253 VGPRs); DESIGN.md 4.2"}
+                    "note": "VALU-bound (PMC: 27.6 VALU per (row, step, state), 76 % busy at 2 waves/SIMD, "
+                            "253 VGPRs); DESIGN.md 4.2"}
         if world == 1 and not args.no_headline:
             del opt
             torch.cuda.empty_cache()
