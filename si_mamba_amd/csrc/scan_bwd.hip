@@ -121,13 +121,15 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_bwd_kernel(ScanArgs p) {
       nvalid = nvalid < 0 ? 0 : (nvalid > kItems ? kItems : nvalid);
       const size_t off = (static_cast<size_t>(b) * D + dc) * L + t0;
 
-      float u[kItems], dl[kItems], zz[kItems], dy[kItems], go[kItems];
+      // dy = dout * silu(z) feeds the adjoint scan; dzw = dout * silu'(z) is kept for the epilogue
+      // (dz = dzw * y_pre), so neither dout nor z stays in registers through the state loop
+      float u[kItems], dl[kItems], dy[kItems], dzw[kItems];
       float ypre[kItems], dxs[kItems], dda[kItems], du[kItems];
       load_items<T, kItems>(ug + off, nvalid, vec, u);
       load_items<T, kItems>(dg + off, nvalid, vec, dl);
-      load_items<T, kItems>(gg + off, nvalid, vec, go);
+      load_items<T, kItems>(gg + off, nvalid, vec, dy);
       const size_t zoff = static_cast<size_t>(dc) * L + t0;
-      if (zg) load_items<T, kItems>(zg + static_cast<size_t>(b) * p.z_bs + zoff, nvalid, vec, zz);
+      if (zg) load_items<T, kItems>(zg + static_cast<size_t>(b) * p.z_bs + zoff, nvalid, vec, dzw);
       float A2[kMaxState];
       load_A_row(p.A + static_cast<size_t>(dc) * N, N, A2);
 
@@ -143,8 +145,14 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_bwd_kernel(ScanArgs p) {
         dl[i] = x;
         sumd += x;
         du[i] = x * u[i];
-        go[i] = (ok && dvalid) ? go[i] : 0.f;
-        dy[i] = zg ? go[i] * zz[i] * sigmoid_f(zz[i]) : go[i];
+        const float go = (ok && dvalid) ? dy[i] : 0.f;
+        if (zg) {
+          const float z = dzw[i], sg = sigmoid_f(z);
+          dy[i] = go * z * sg;
+          dzw[i] = go * sg * (1.f + z * (1.f - sg));
+        } else {
+          dy[i] = go;
+        }
         ypre[i] = Dd * u[i];
         dxs[i] = 0.f;
         dda[i] = 0.f;
@@ -253,10 +261,7 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_bwd_kernel(ScanArgs p) {
         sBias += gd;
         sD = fmaf(dy[i], u[i], sD);
         du[i] = fmaf(dl[i], dxs[i], Dd * dy[i]);
-        if (zg) {
-          const float s = sigmoid_f(zz[i]);
-          dzv[i] = go[i] * ypre[i] * s * (1.f + zz[i] * (1.f - s));
-        }
+        if (zg) dzv[i] = dzw[i] * ypre[i];
       }
       if (dvalid) {
         store_items<T, kItems>(dug + off, nvalid, vec, du);
