@@ -132,6 +132,12 @@ int simamba_selective_scan_bwd(const void* u, const void* delta, const float* A,
 int simamba_xdt_proj_fwd(const void* x, const float* wx, const float* wdt, void* xdbl, void* delta,
                          int batch, int D, int seqlen, int S, int R, int io_dtype, long long x_bstride,
                          void* stream);
+/* The same with the causal depthwise conv1d (width 4, bias cb or NULL, + SiLU) of the mixer applied to x on the way
+ * in (causal_conv1d_fn inside the same mamba_inner_fn): xconv (batch, D, seqlen) receives silu(conv(x)) -- what the
+ * scan and the backward read -- so conv, x_proj and dt_proj are one pass over the in_proj output's x half. */
+int simamba_conv_xdt_proj_fwd(const void* x, const float* cw, const float* cb, const float* wx, const float* wdt,
+                              void* xconv, void* xdbl, void* delta, int batch, int D, int seqlen, int S, int R,
+                              int io_dtype, long long x_bstride, void* stream);
 
 /*
  * Token-sequence expansion along the last axis and its adjoint.  The reference's block stack sees L = 2 k G tokens

@@ -41,6 +41,8 @@ SIGNATURES = {
                                            c_int, c_int, c_int, c_int, c_int, c_int,
                                            _LL, _LL, _LL, _LL, _LL, _P]),
     "simamba_xdt_proj_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _LL, _P]),
+    "simamba_conv_xdt_proj_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _LL,
+                                          _P]),
     "simamba_seq_gather_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _LL, c_int, _P]),
     "simamba_seq_gather_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _LL, c_int, _P]),
     "simamba_causal_conv1d_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _LL, _P]),

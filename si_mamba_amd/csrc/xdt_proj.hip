@@ -34,7 +34,10 @@ constexpr int kWP = kKS + 4;      // pitch of the Wx tile (floats)
 constexpr int kSPad = 64;         // S padded to two 32-row blocks
 
 struct XdtArgs {
-  const float* x;        // (batch, D, L)
+  const float* x;        // (batch, D, L); with kConv: the conv INPUT (x half of the in_proj output)
+  const float* cw;       // kConv: (D, 4) depthwise taps
+  const float* cb;       // kConv: (D) bias or NULL
+  float* xconv;          // kConv: (batch, D, L) silu(conv(x)) written as a by-product
   const float* wx;       // (S, D)
   const float* wdt;      // (D, R)
   float* xdbl;           // (batch, L, S)
@@ -43,6 +46,13 @@ struct XdtArgs {
   long long x_bs;        // batch stride of x (elements)
 };
 
+// kConv: the causal depthwise conv1d (width 4) + SiLU that precedes x_proj in the mixer runs while the x tile is
+// staged -- same arithmetic as conv1d_fwd_kernel (fmaf chain over the taps, x * sigmoid(x)) -- and its result is both
+// the GEMM operand and, stored once, the conv output the scan and the backward read: the separate conv launch and its
+// re-read of the activation disappear.  A thread's 4-step pack needs the 3 steps before it: the previous pack of the
+// row sits in the neighbouring lane (DPP row_shr:1; a tile row is exactly one 16-lane DPP row) except for the row's
+// first pack, which reads the 16 bytes in front of the tile (zeros at t = 0).
+template <bool kConv>
 __global__ __launch_bounds__(kXdtThreads, 2) void xdt_proj_f32_kernel(XdtArgs p) {
   __shared__ __attribute__((aligned(16))) float sX[2][kKS * kTok];       // [d][t]
   __shared__ __attribute__((aligned(16))) float sW[2][kSPad * kWP];      // [s][d], padded pitch
@@ -51,9 +61,14 @@ __global__ __launch_bounds__(kXdtThreads, 2) void xdt_proj_f32_kernel(XdtArgs p)
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, hh = lane >> 5;
   const int sblk = wave & 1, tblk = wave >> 1;
-  const int b = blockIdx.y;
-  const int t0 = blockIdx.x * kTok;
   const int D = p.D, L = p.L, S = p.S, R = p.R;
+  // A workgroup walks tiles blockIdx.x, + gridDim.x, ...: the host sizes the grid so that every workgroup gets the same
+  // number of tiles and all of them are resident at once (2 - 3 per CU).  With one tile per workgroup 1024 tiles on 768
+  // resident slots ran as a full round plus a quarter-full one in which each SIMD's matrix pipe served a single wave.
+  const int tps = (L + kTok - 1) / kTok;                  // tiles per sample
+  for (int tile = blockIdx.x; tile < p.batch * tps; tile += gridDim.x) {
+  const int b = tile / tps;
+  const int t0 = (tile - b * tps) * kTok;
   const float* __restrict__ xg = p.x + static_cast<size_t>(b) * p.x_bs;
 
   // ---- staging identities ---------------------------------------------------------------------------------------
@@ -62,22 +77,59 @@ __global__ __launch_bounds__(kXdtThreads, 2) void xdt_proj_f32_kernel(XdtArgs p)
   const bool xok = t0 + xt < L;                           // L % 4 == 0: a pack is all in or all out
   // Wx tile: 64 s x 32 d = 512 float4; thread -> (s = tid >> 3 (+32), d4 = 4 (tid & 7))
   const int ws = tid >> 3, wd = 4 * (tid & 7);
-  float4 rx[2], rw[2];
+  float4 rx[2], rw[2], rh[2], rt[2];
+  float rb[2];
   auto gload = [&](int k0) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int d = k0 + xd + 16 * j;
       rx[j] = xok ? *reinterpret_cast<const float4*>(xg + static_cast<size_t>(d) * L + t0 + xt)
                   : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (kConv) {
+        // the pack in front of the tile (used by the row's first lane only; one address per 16-lane row) and the taps
+        rh[j] = t0 > 0 ? *reinterpret_cast<const float4*>(xg + static_cast<size_t>(d) * L + t0 - 4)
+                       : make_float4(0.f, 0.f, 0.f, 0.f);
+        rt[j] = *reinterpret_cast<const float4*>(p.cw + static_cast<size_t>(d) * 4);
+        rb[j] = p.cb ? p.cb[d] : 0.f;
+      }
       const int s = ws + 32 * j;
       rw[j] = s < S ? *reinterpret_cast<const float4*>(p.wx + static_cast<size_t>(s) * D + k0 + wd)
                     : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
-  auto lstore = [&](int buf) {
+  auto lstore = [&](int buf, int k0) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      *reinterpret_cast<float4*>(&sX[buf][(xd + 16 * j) * kTok + xt]) = rx[j];
+      float4 v = rx[j];
+      if (kConv) {
+        // previous pack of the row: the neighbouring lane's current pack (lane16 == 0: the halo load)
+        // The three DPP reads run with EVERY lane active and are pinned in front of the select: a DPP read of a lane
+        // that is masked off returns the `old` operand, and hipcc, left alone, predicates the false arm of a ternary
+        // (lane 1 of every row then read zeros from the masked-off lane 0: t0 + 4 .. 6 of every tile came out wrong).
+        const bool first = (tid & 15) == 0;
+        float q1 = dpp<DPP_ROW_SHR + 1>(0.f, rx[j].y);
+        float q2 = dpp<DPP_ROW_SHR + 1>(0.f, rx[j].z);
+        float q3 = dpp<DPP_ROW_SHR + 1>(0.f, rx[j].w);
+        asm volatile("" : "+v"(q1), "+v"(q2), "+v"(q3));
+        const float p1 = first ? rh[j].y : q1;
+        const float p2 = first ? rh[j].z : q2;
+        const float p3 = first ? rh[j].w : q3;
+        const float win[7] = {p1, p2, p3, rx[j].x, rx[j].y, rx[j].z, rx[j].w};
+        const float w4[4] = {rt[j].x, rt[j].y, rt[j].z, rt[j].w};
+        float o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float acc = rb[j];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc = fmaf(w4[q], win[i + q], acc);
+          o[i] = acc * sigmoid_f(acc);
+        }
+        v = make_float4(o[0], o[1], o[2], o[3]);
+        if (xok)
+          *reinterpret_cast<float4*>(p.xconv + (static_cast<size_t>(b) * D + k0 + xd + 16 * j) * L + t0 + xt) = v;
+        if (!xok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      *reinterpret_cast<float4*>(&sX[buf][(xd + 16 * j) * kTok + xt]) = v;
       *reinterpret_cast<float4*>(&sW[buf][(ws + 32 * j) * kWP + wd]) = rw[j];
     }
   };
@@ -92,7 +144,7 @@ __global__ __launch_bounds__(kXdtThreads, 2) void xdt_proj_f32_kernel(XdtArgs p)
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
   const int nk = D / kKS;
   gload(0);
-  lstore(0);
+  lstore(0, 0);
   __syncthreads();
   for (int ks = 0; ks < nk; ++ks) {
     const int buf = ks & 1;
@@ -109,7 +161,7 @@ __global__ __launch_bounds__(kXdtThreads, 2) void xdt_proj_f32_kernel(XdtArgs p)
     for (int m = 0; m < 16; ++m) bv[m] = bx[m * kTok];
 #pragma unroll
     for (int m = 0; m < 16; ++m) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bv[m], acc, 0, 0, 0);
-    if (ks + 1 < nk) lstore(buf ^ 1);
+    if (ks + 1 < nk) lstore(buf ^ 1, (ks + 1) * kKS);
     __syncthreads();
   }
 
@@ -179,31 +231,60 @@ __global__ __launch_bounds__(kXdtThreads, 2) void xdt_proj_f32_kernel(XdtArgs p)
 #pragma unroll
     for (int g = 0; g < 3; ++g) wa[g] = wn[g];
   }
+  __syncthreads();                                         // sDt (= the first x tile buffer) is refilled by the next tile
+  }
 }
 
 }  // namespace simamba
 
 using namespace simamba;
 
-// fp32 only (bf16 mixers keep the library GEMMs); D % 32 == 0, L % 4 == 0, S % 4 == 0, S <= 64, R % 4 == 0, R <= 24.
-extern "C" int simamba_xdt_proj_fwd(const void* x, const float* wx, const float* wdt, void* xdbl, void* delta,
-                                    int batch, int D, int L, int S, int R, int io_dtype, long long x_bstride,
-                                    void* stream) {
+static int xdt_launch(const void* x, const float* cw, const float* cb, const float* wx, const float* wdt, void* xconv,
+                      void* xdbl, void* delta, int batch, int D, int L, int S, int R, int io_dtype,
+                      long long x_bstride, bool conv, void* stream) {
   if (batch < 0 || D <= 0 || L < 0 || batch > 65535) return SIMAMBA_E_SHAPE;
   if (io_dtype != SIMAMBA_F32) return SIMAMBA_E_DTYPE;
   if (D % 32 || L % 4 || S % 4 || S > kSPad || S < R || R % 4 || R > 24 || R < 4) return SIMAMBA_E_SHAPE;
   if (batch == 0 || L == 0) return SIMAMBA_OK;
-  if (!x || !wx || !wdt || !xdbl || !delta) return SIMAMBA_E_NULLPTR;
-  const uintptr_t al = reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(wx) | reinterpret_cast<uintptr_t>(wdt) |
-                       reinterpret_cast<uintptr_t>(xdbl) | reinterpret_cast<uintptr_t>(delta);
+  if (!x || !wx || !wdt || !xdbl || !delta || (conv && (!cw || !xconv))) return SIMAMBA_E_NULLPTR;
+  uintptr_t al = reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(wx) | reinterpret_cast<uintptr_t>(wdt) |
+                 reinterpret_cast<uintptr_t>(xdbl) | reinterpret_cast<uintptr_t>(delta);
+  if (conv) al |= reinterpret_cast<uintptr_t>(cw) | reinterpret_cast<uintptr_t>(xconv);
   if (al & 15u) return SIMAMBA_E_ALIGN;
   XdtArgs a{};
-  a.x = static_cast<const float*>(x); a.wx = wx; a.wdt = wdt;
+  a.x = static_cast<const float*>(x); a.wx = wx; a.wdt = wdt; a.cw = cw; a.cb = cb;
+  a.xconv = static_cast<float*>(xconv);
   a.xdbl = static_cast<float*>(xdbl); a.delta = static_cast<float*>(delta);
   a.batch = batch; a.D = D; a.L = L; a.S = S; a.R = R;
   a.x_bs = x_bstride ? x_bstride : static_cast<long long>(D) * L;
   if (a.x_bs % 4) return SIMAMBA_E_ALIGN;
-  dim3 grid((L + kTok - 1) / kTok, batch);
-  hipLaunchKernelGGL(xdt_proj_f32_kernel, grid, dim3(kXdtThreads), 0, static_cast<hipStream_t>(stream), a);
+  // grid: every workgroup the same number of tiles, all workgroups resident together (3 fit per CU, 256 CUs)
+  const long long ntiles = static_cast<long long>(batch) * ((L + kTok - 1) / kTok);
+  long long g = ntiles;
+  if (ntiles > 768) {
+    long long per = (ntiles + 767) / 768;                  // tiles per workgroup at full residency
+    while (ntiles % per) ++per;                            // ... evened out (per divides ntiles)
+    g = ntiles / per;
+  }
+  dim3 grid(static_cast<unsigned>(g));
+  if (conv)
+    hipLaunchKernelGGL(xdt_proj_f32_kernel<true>, grid, dim3(kXdtThreads), 0, static_cast<hipStream_t>(stream), a);
+  else
+    hipLaunchKernelGGL(xdt_proj_f32_kernel<false>, grid, dim3(kXdtThreads), 0, static_cast<hipStream_t>(stream), a);
   return static_cast<int>(hipGetLastError());
+}
+
+// fp32 only (bf16 mixers keep the library GEMMs); D % 32 == 0, L % 4 == 0, S % 4 == 0, S <= 64, R % 4 == 0, R <= 24.
+extern "C" int simamba_xdt_proj_fwd(const void* x, const float* wx, const float* wdt, void* xdbl, void* delta,
+                                    int batch, int D, int L, int S, int R, int io_dtype, long long x_bstride,
+                                    void* stream) {
+  return xdt_launch(x, nullptr, nullptr, wx, wdt, nullptr, xdbl, delta, batch, D, L, S, R, io_dtype, x_bstride, false,
+                    stream);
+}
+
+// The same with the mixer's causal depthwise conv1d (width 4, + SiLU) applied to x on the way in; xconv receives it.
+extern "C" int simamba_conv_xdt_proj_fwd(const void* x, const float* cw, const float* cb, const float* wx,
+                                         const float* wdt, void* xconv, void* xdbl, void* delta, int batch, int D, int L,
+                                         int S, int R, int io_dtype, long long x_bstride, void* stream) {
+  return xdt_launch(x, cw, cb, wx, wdt, xconv, xdbl, delta, batch, D, L, S, R, io_dtype, x_bstride, true, stream);
 }

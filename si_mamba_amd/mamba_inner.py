@@ -89,9 +89,11 @@ def xdt_proj_fused_ok(x, wx, wdt):
             and R % 4 == 0 and 4 <= R <= 24 and S >= R and wdt.shape[0] == D and x.data_ptr() % 16 == 0)
 
 
-def xdt_proj_fwd(x, wx, wdt):
-    """x (B, D, L) fp32, wx (S, D), wdt (D, R) -> x_dbl (B, L, S) token-major, delta (B, D, L).  No autograd: called
-    from inside MambaInnerFn.forward, whose backward differentiates the two products itself."""
+def xdt_proj_fwd(x, wx, wdt, conv=None):
+    """x (B, D, L) fp32 (batch-strided views allowed), wx (S, D), wdt (D, R) -> x_dbl (B, L, S) token-major, delta
+    (B, D, L).  ``conv=(w (D, 4) fp32, bias (D) or None, out (B, D, L))``: the causal depthwise conv1d + SiLU is applied
+    to x on the way in and its result written to ``out``.  No autograd: called from inside MambaInnerFn.forward, whose
+    backward differentiates the products itself."""
     lib = _lib.load()
     Bsz, D, L = x.shape
     S, R = wx.shape[0], wdt.shape[1]
@@ -99,8 +101,15 @@ def xdt_proj_fwd(x, wx, wdt):
     x_dbl = torch.empty(Bsz, L, S, device=x.device, dtype=x.dtype)
     delta = torch.empty(Bsz, D, L, device=x.device, dtype=x.dtype)
     with torch.cuda.device(x.device), _lib.timed("xdt_proj_fwd", x.device):
-        rc = lib.simamba_xdt_proj_fwd(x.data_ptr(), wxc.data_ptr(), wdc.data_ptr(), x_dbl.data_ptr(), delta.data_ptr(),
-                                      Bsz, D, L, S, R, _lib.F32, x.stride(0), _lib.stream_ptr(x.device))
+        if conv is None:
+            rc = lib.simamba_xdt_proj_fwd(x.data_ptr(), wxc.data_ptr(), wdc.data_ptr(), x_dbl.data_ptr(),
+                                          delta.data_ptr(), Bsz, D, L, S, R, _lib.F32, x.stride(0),
+                                          _lib.stream_ptr(x.device))
+        else:
+            cw, cb, out = conv
+            rc = lib.simamba_conv_xdt_proj_fwd(x.data_ptr(), cw.data_ptr(), _lib.ptr(cb), wxc.data_ptr(), wdc.data_ptr(),
+                                               out.data_ptr(), x_dbl.data_ptr(), delta.data_ptr(), Bsz, D, L, S, R,
+                                               _lib.F32, x.stride(0), _lib.stream_ptr(x.device))
     _lib.check(rc, "simamba_xdt_proj_fwd")
     return x_dbl, delta
 
@@ -131,20 +140,23 @@ class MambaInnerFn(torch.autograd.Function):
         bf = None if delta_bias is None else delta_bias.float().contiguous()
         W = cw.shape[1]
 
-        x_conv = torch.empty(Bsz, Dm, L, device=dev, dtype=io)
-        with torch.cuda.device(dev), _lib.timed("conv1d_fwd", dev):
-            rc = lib.simamba_causal_conv1d_fwd(x_in.data_ptr(), cw.data_ptr(), _lib.ptr(cb), x_conv.data_ptr(),
-                                               Bsz, Dm, L, W, 1, code, xbs, stream)
-        _lib.check(rc, "simamba_causal_conv1d_fwd")
-
         xw_c, dtw_c, ow_c = _w(x_proj_w, io), _w(dt_proj_w, io), _w(out_proj_w, io)   # compute-dtype weights,
         ctx.wcast = (xw_c, dtw_c, ow_c)                                               # reused by backward
-        if xdt_proj_fused_ok(x_conv, xw_c, dtw_c):
-            # x_proj -> dt_proj as ONE pass over x_conv on the matrix cores (csrc/xdt_proj.hip)
-            x_dbl, delta = xdt_proj_fwd(x_conv, xw_c, dtw_c)
+        x_conv = torch.empty(Bsz, Dm, L, device=dev, dtype=io)
+        if W == 4 and xdt_proj_fused_ok(x_in, xw_c, dtw_c):
+            # conv1d + SiLU -> x_proj -> dt_proj as ONE pass over the x half of xz on the matrix cores
+            # (csrc/xdt_proj.hip); x_conv is written as a by-product for the scan and the backward
+            x_dbl, delta = xdt_proj_fwd(x_in, xw_c, dtw_c, conv=(cw, cb, x_conv))
         else:
-            x_dbl = _xw(x_conv.transpose(1, 2), xw_c.t())                              # (B, L, S)
-            delta = _wx(dtw_c, x_dbl[:, :, :R].transpose(1, 2))                        # (B, D, L)
+            with torch.cuda.device(dev), _lib.timed("conv1d_fwd", dev):
+                rc = lib.simamba_causal_conv1d_fwd(x_in.data_ptr(), cw.data_ptr(), _lib.ptr(cb), x_conv.data_ptr(),
+                                                   Bsz, Dm, L, W, 1, code, xbs, stream)
+            _lib.check(rc, "simamba_causal_conv1d_fwd")
+            if xdt_proj_fused_ok(x_conv, xw_c, dtw_c):
+                x_dbl, delta = xdt_proj_fwd(x_conv, xw_c, dtw_c)
+            else:
+                x_dbl = _xw(x_conv.transpose(1, 2), xw_c.t())                          # (B, L, S)
+                delta = _wx(dtw_c, x_dbl[:, :, :R].transpose(1, 2))                    # (B, D, L)
         Bv, Cv = x_dbl[:, :, R:R + N], x_dbl[:, :, R + N:]                            # (B, L, N) views
 
         nchunks = lib.simamba_scan_num_chunks(L)

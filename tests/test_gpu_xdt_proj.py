@@ -54,12 +54,12 @@ def test_mixer_uses_the_fused_kernel_and_matches_the_library_route(device, monke
     h = torch.randn(2, 256, 384, device=device)
     calls = []
     real = mamba_inner.xdt_proj_fwd
-    monkeypatch.setattr(mamba_inner, "xdt_proj_fwd", lambda *a: (calls.append(1), real(*a))[1])
+    monkeypatch.setattr(mamba_inner, "xdt_proj_fwd", lambda *a, **k: (calls.append(k), real(*a, **k))[1])
     h1 = h.clone().requires_grad_(True)
     o1 = m(h1)
     o1.sum().backward()
     g1 = {k: p.grad.clone() for k, p in m.named_parameters()}
-    assert calls, "fp32 mixer forward did not take the fused x_proj -> dt_proj kernel"
+    assert calls and calls[0].get("conv") is not None, "fp32 mixer forward did not take the fused conv + x_proj + dt_proj kernel"
     m.zero_grad(set_to_none=True)
     monkeypatch.setattr(mamba_inner, "xdt_proj_fused_ok", lambda *a: False)
     h2 = h.clone().requires_grad_(True)
@@ -68,3 +68,35 @@ def test_mixer_uses_the_fused_kernel_and_matches_the_library_route(device, monke
     assert nerr(o1, o2) < 1e-5 and nerr(h1.grad, h2.grad) < 1e-5
     for k, p in m.named_parameters():
         assert nerr(g1[k], p.grad) < 1e-4, k
+
+
+@pytest.mark.parametrize("B,D,L", [(2, 768, 1024), (3, 256, 68), (1, 64, 4), (64, 768, 1024)])
+@pytest.mark.parametrize("bias", [True, False])
+def test_conv_fused_into_the_staging_matches_the_conv_kernel(B, D, L, bias, device):
+    """simamba_conv_xdt_proj_fwd: the conv output written as a by-product equals the stand-alone conv kernel's bit for
+    bit (same fmaf chain), x_dbl / delta equal the unfused kernel's on that conv output, and everything matches the
+    oracle's conv + float64 products on a few samples."""
+    from oracle import scan_ref
+    from si_mamba_amd import causal_conv1d_fn
+    from si_mamba_amd.mamba_inner import xdt_proj_fwd
+    N, R = 16, (24 if D == 768 else 8)
+    S = R + 2 * N
+    g = torch.Generator().manual_seed(L)
+    xz = torch.randn(B, 2 * D, L, generator=g).to(device)
+    x_in = xz[:, :D]
+    cw = (torch.randn(D, 4, generator=g) * 0.5).to(device)
+    cb = torch.randn(D, generator=g).to(device) if bias else None
+    wx = (torch.randn(S, D, generator=g) / D ** 0.5).to(device)
+    wdt = (torch.randn(D, R, generator=g) / R ** 0.5).to(device)
+    x_conv = torch.empty(B, D, L, device=device)
+    x_dbl, delta = xdt_proj_fwd(x_in, wx, wdt, conv=(cw, cb, x_conv))
+    want_conv = causal_conv1d_fn(x_in, cw, cb, "silu")
+    assert torch.equal(x_conv, want_conv)
+    x_dbl2, delta2 = xdt_proj_fwd(want_conv, wx, wdt)
+    assert torch.equal(x_dbl, x_dbl2) and torch.equal(delta, delta2)
+    sel = [0, B - 1]
+    oc = scan_ref.causal_conv1d_ref(x_in[sel].cpu(), cw.cpu(), None if cb is None else cb.cpu(), "silu")
+    assert nerr(x_conv[sel], oc) < 1e-5
+    want_dbl = torch.einsum("sd,bdt->bts", wx.cpu().double(), oc.double())
+    assert nerr(x_dbl[sel], want_dbl) < 1e-5
+    assert nerr(delta[sel], torch.einsum("dr,btr->bdt", wdt.cpu().double(), want_dbl[:, :, :R])) < 1e-5

@@ -35,3 +35,25 @@ for B, D, L, N, R in [(64, 768, 1024, 16, 24), (128, 768, 1024, 16, 24), (64, 76
         print(f"({B},{D},{L}) {name:20s} {us:8.1f} us  {flops / us * 1e-6:6.1f} TF/s  {nbytes / us * 1e-3:7.1f} GB/s", flush=True)
     a, b = lib(), fused()
     print("   max |diff| x_dbl %.2e delta %.2e" % ((a[0] - b[0]).abs().max().item(), (a[1] - b[1]).abs().max().item()))
+
+# the conv-fused form against conv kernel + fused projections
+from si_mamba_amd import causal_conv1d_fn
+for B, D, L in [(64, 768, 1024), (128, 768, 1024)]:
+    xz = torch.randn(B, 2 * D, L, device=dev)
+    x_in = xz[:, :D]
+    cw = torch.randn(D, 4, device=dev) * 0.5
+    cb = torch.randn(D, device=dev)
+    wx = torch.randn(56, D, device=dev) / D ** 0.5
+    wdt = torch.randn(D, 24, device=dev) / 24 ** 0.5
+    xc = torch.empty(B, D, L, device=dev)
+    for name, fn in (("conv kernel + xdt kernel", lambda: xdt_proj_fwd(causal_conv1d_fn(x_in, cw, cb, "silu"), wx, wdt)),
+                     ("conv fused into xdt", lambda: xdt_proj_fwd(x_in, wx, wdt, conv=(cw, cb, xc)))):
+        for _ in range(3):
+            fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(20):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        print(f"({B},{D},{L}) {name:26s} {a.elapsed_time(b) * 1e3 / 20:8.1f} us", flush=True)
