@@ -127,14 +127,17 @@ int simamba_selective_scan_bwd(const void* u, const void* delta, const float* A,
  *   delta[b, d, t] = sum_r wdt[d, r] * xdbl[b, t, r], r < R (batch, D, seqlen)
  *   x : (batch, D, seqlen), seqlen contiguous, batch stride x_bstride elements (0 => D * seqlen);
  *   wx : (S, D) fp32 ; wdt : (D, R) fp32.  SIMAMBA_F32 only (exact fp32 MFMA, v_mfma_f32_32x32x2_f32);
- *   D % 32 == 0, seqlen % 4 == 0, S % 4 == 0, S <= 64, R % 4 == 0, 4 <= R <= 24, 16-byte aligned pointers.
+ *   D % 64 == 0, D * seqlen * 4 < 2^32 (one sample is one buffer descriptor), seqlen % 4 == 0, S % 4 == 0, S <= 64,
+ *   R % 4 == 0, 4 <= R <= 24, 16-byte aligned pointers; anything else returns SIMAMBA_E_SHAPE / _ALIGN (the host
+ *   mirror then takes the two library GEMMs).
  */
 int simamba_xdt_proj_fwd(const void* x, const float* wx, const float* wdt, void* xdbl, void* delta,
                          int batch, int D, int seqlen, int S, int R, int io_dtype, long long x_bstride,
                          void* stream);
 /* The same with the causal depthwise conv1d (width 4, bias cb or NULL, + SiLU) of the mixer applied to x on the way
  * in (causal_conv1d_fn inside the same mamba_inner_fn): xconv (batch, D, seqlen) receives silu(conv(x)) -- what the
- * scan and the backward read -- so conv, x_proj and dt_proj are one pass over the in_proj output's x half. */
+ * scan and the backward read -- so conv, x_proj and dt_proj are one pass over the in_proj output's x half.
+ * D <= 1024 (taps and bias are held in LDS). */
 int simamba_conv_xdt_proj_fwd(const void* x, const float* cw, const float* cb, const float* wx, const float* wdt,
                               void* xconv, void* xdbl, void* delta, int batch, int D, int seqlen, int S, int R,
                               int io_dtype, long long x_bstride, void* stream);

@@ -7,21 +7,22 @@
 // with x = the conv output (batch, D, L), L contiguous.  Two library GEMMs become one pass over x:
 //   * x_dbl leaves token-major, (batch, L, S): B_t | C_t sit where the scan kernels read them (state stride 1);
 //   * delta leaves (batch, D, L), L contiguous, the layout the scan streams.
-// One 256-thread workgroup owns 64 consecutive tokens of one sample.
+// A 256-thread workgroup walks 64-token tiles of one sample each (all workgroups resident: 2 per CU).
 //   phase 1  Y[s, t] = sum_d Wx[s, d] x[d, t]: K = D in steps of 32 through double-buffered LDS tiles; wave w owns the
 //            32 x 32 block (s-block w & 1, t-block w >> 1).  A-operand lane map of the 32x32x2 MFMA is
 //            A[i = lane & 31][k = lane >> 5]: which two d's an MFMA contracts is free as long as A and B agree, so
 //            lanes < 32 take d = 0..15 of the step and lanes >= 32 take d = 16..31: a lane's 16 A values are 64
 //            contiguous bytes of a Wx row (4 ds_read_b128; 36-float pitch: conflict-free), its 16 B values one
-//            column of the x tile (16 ds_read_b32, lanes on consecutive t).
-//   phase 2  delta[d, t] = sum_r Wdt[d, r] Y[r, t], K = R = 24 = 12 MFMAs per 32 x 32 block.  The dt rows of Y go
-//            through LDS once (6 KB) and stay in registers as B operands; the A operand, Wdt[d][8g + 4h .. + 3], is
-//            three 16-byte loads per lane and d-block straight from global memory (74 KB table, L2 resident), issued
-//            one d-block ahead.  The accumulator's C/D layout (col = lane & 31, row = (reg & 3) + 8 (reg >> 2) +
-//            4 (lane >> 5)) puts a store instruction on two rows x 128 contiguous bytes of delta.
-// Algorithmic bytes per token: read 4 D, write 4 D + 4 S (6.4 KB); flops 2 S D + 2 D R = 123 K: close to the ridge
-// of fp32 MFMA (157 TF/s) against HBM.
+//            column of the x tile (8 ds_read2st64_b32, lanes on consecutive t).
+//   phase 2  delta[d, t] = sum_r Wdt[d, r] Y[r, t], K = R = 24 = 12 MFMAs per 32 x 32 block, run for the PREVIOUS tile
+//            inside phase 1 of the next one (see Schedule below).  The dt rows of Y wait in LDS (6 KB); the A operand,
+//            Wdt[d][8g + 4h .. + 3], is three 16-byte loads per lane and d-block straight from global memory (74 KB
+//            table, L2 resident), issued one unit ahead.  The accumulator's C/D layout (col = lane & 31, row =
+//            (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)) puts a store instruction on two rows x 128 contiguous bytes.
+// Algorithmic bytes per token: read 4 D, write 4 D + 4 S (6.4 KB; with the conv fused another 4 D written); flops
+// 2 S D + 2 D R = 123 K: close to the ridge of fp32 MFMA (157 TF/s) against HBM.
 #include "common.h"
+#include <type_traits>
 
 namespace simamba {
 
@@ -51,187 +52,334 @@ struct XdtArgs {
 // the GEMM operand and, stored once, the conv output the scan and the backward read: the separate conv launch and its
 // re-read of the activation disappear.  A thread's 4-step pack needs the 3 steps before it: the previous pack of the
 // row sits in the neighbouring lane (DPP row_shr:1; a tile row is exactly one 16-lane DPP row) except for the row's
-// first pack, which reads the 16 bytes in front of the tile (zeros at t = 0).
+// first pack, which reads the 16 bytes in front of the tile (zeros at t = 0).  Taps and bias sit in LDS.
+//
+// Schedule.  The first form of this kernel ran load -> LDS -> 16 MFMAs -> barrier per step and phase 2 after phase 1:
+// 51 % matrix-pipe busy, phase 1 + phase 2 = 72 + 50 us with nothing of the one under the other (a dependent chain of
+// these MFMAs alone reaches 89 % of the pipe: tools/mfma_probe.hip, so the chain is not the limit -- what sits between
+// the bursts is).  Now every wave overlaps its own work, four steps deep (a step = 32 d of one tile; g counts steps
+// across the tiles a workgroup walks):
+//     iteration g:   16 MFMAs of step g                          (operand registers read in iteration g - 1)
+//                    one 32 x 32 block of delta of the PREVIOUS tile every other iteration (12 MFMAs, 16 row stores)
+//                    conv + LDS store of step g + 2              (global loads issued in iteration g - 2 -> buffer g & 1)
+//                    issue the global loads of step g + 4
+//                    ds_read the operands of step g + 1          (tile buffer (g + 1) & 1 -> the registers just used)
+//                    one barrier
+// so the x reads, the x_conv / delta writes and the matrix pipe run for the whole kernel instead of taking turns; only
+// the last tile's delta blocks are left for a tail.  The body of an iteration is ONE basic block: every global access
+// is a buffer instruction whose out-of-range lanes (tile edge, rows past S or R, steps past the last tile: the
+// descriptor of such a step has zero records) load zeros / store nothing, so nothing in it branches, hipcc's scheduler
+// lays the VALU and memory work between the MFMAs, and its s_waitcnt bookkeeping comes out counted (vmcnt(N), the
+// loads of the two steps ahead stay in flight) where predicated loads made it drain to vmcnt(0) at every use.
+// Measured at (64, 768, 1024) by elimination (tools/xdt_probe.hip): with the MFMAs removed the kernel
+// takes 101 us (plain) / 167 us (conv) of its 118 / 180 us -- it is bound by how many bytes 8 waves per CU keep in
+// flight around a per-step barrier, not by the matrix pipe or the instruction order (sched_group_barrier / iglp_opt
+// interleaves: no change).
+constexpr int kMaxDConv = 1024;   // taps + bias of the fused conv live in LDS (20 KB)
+constexpr unsigned kOob = 0xfffff000u;   // a byte offset past every descriptor's range
+
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+
+__device__ __forceinline__ rsrc_t make_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, static_cast<int>(bytes), 0x00020000);
+}
+// The 128-bit builtins' own vector type, reached by bit_cast only: initialising an ext_vector_type(4) from the
+// builtin's result compiles (hipcc, ROCm 7.2) to a ONE-dword load splatted over the four lanes.
+using bvec4_t = decltype(__builtin_amdgcn_raw_buffer_load_b128(make_rsrc(nullptr, 0u), 0u, 0u, 0));
+__device__ __forceinline__ float4 bload4(rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ void bstore4(float4 f, rsrc_t r, unsigned voff, unsigned soff) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(bvec4_t, f), r, voff, soff, 0);
+}
+__device__ __forceinline__ void bstore1(float f, rsrc_t r, unsigned voff, unsigned soff) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, f), r, voff, soff, 0);
+}
+
+// A step of the walk: tile `j` of this workgroup (sample q, tile r of the sample), step ks of it.  Advancing never divides.
+struct Cursor {
+  int j, ks, q, r;
+};
+
 template <bool kConv>
 __global__ __launch_bounds__(kXdtThreads, 2) void xdt_proj_f32_kernel(XdtArgs p) {
   __shared__ __attribute__((aligned(16))) float sX[2][kKS * kTok];       // [d][t]
   __shared__ __attribute__((aligned(16))) float sW[2][kSPad * kWP];      // [s][d], padded pitch
+  __shared__ __attribute__((aligned(16))) float sDt[24 * kTok];          // dt rows of the tile just finished [r][t]
+  __shared__ __attribute__((aligned(16))) float sTap[kConv ? kMaxDConv * 4 : 4];
+  __shared__ float sBias[kConv ? kMaxDConv : 1];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, hh = lane >> 5;
   const int sblk = wave & 1, tblk = wave >> 1;
   const int D = p.D, L = p.L, S = p.S, R = p.R;
-  // A workgroup walks tiles blockIdx.x, + gridDim.x, ...: the host sizes the grid so that every workgroup gets the same
-  // number of tiles and all of them are resident at once (2 - 3 per CU).  With one tile per workgroup 1024 tiles on 768
-  // resident slots ran as a full round plus a quarter-full one in which each SIMD's matrix pipe served a single wave.
   const int tps = (L + kTok - 1) / kTok;                  // tiles per sample
-  for (int tile = blockIdx.x; tile < p.batch * tps; tile += gridDim.x) {
-  const int b = tile / tps;
-  const int t0 = (tile - b * tps) * kTok;
-  const float* __restrict__ xg = p.x + static_cast<size_t>(b) * p.x_bs;
+  const int ntiles = p.batch * tps;
+  const int nwg = static_cast<int>(gridDim.x), wg = static_cast<int>(blockIdx.x);
+  // this workgroup's tiles: wg, wg + nwg, ... (the host evens the counts out and keeps all workgroups resident)
+  const int ntw = (ntiles - wg + nwg - 1) / nwg;
+  if (ntw <= 0) return;
+  const int nk = D / kKS;                                 // steps per tile; even (host: D % 64 == 0)
+  const int ndb = D / 32;                                 // 32-channel blocks of delta; wave w owns w, w + 4, ...
+  const int nunits = wave < ndb ? 2 * ((ndb - wave + 3) / 4) : 0;   // (d-block, token block) units of this wave per tile
+  const int gq = nwg / tps, gr = nwg - gq * tps;          // the tile stride nwg as (samples, tiles of a sample)
+  const unsigned sample_bytes = static_cast<unsigned>(D) * static_cast<unsigned>(L) * 4u;   // host: < 2^32
 
-  // ---- staging identities ---------------------------------------------------------------------------------------
-  // x tile: 32 d x 64 t = 512 float4; thread -> (d = tid >> 4 (+16), t4 = 4 (tid & 15))
-  const int xd = tid >> 4, xt = 4 * (tid & 15);
-  const bool xok = t0 + xt < L;                           // L % 4 == 0: a pack is all in or all out
-  // Wx tile: 64 s x 32 d = 512 float4; thread -> (s = tid >> 3 (+32), d4 = 4 (tid & 7))
-  const int ws = tid >> 3, wd = 4 * (tid & 7);
-  float4 rx[2], rw[2], rh[2], rt[2];
-  float rb[2];
-  auto gload = [&](int k0) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int d = k0 + xd + 16 * j;
-      rx[j] = xok ? *reinterpret_cast<const float4*>(xg + static_cast<size_t>(d) * L + t0 + xt)
-                  : make_float4(0.f, 0.f, 0.f, 0.f);
-      if (kConv) {
-        // the pack in front of the tile (used by the row's first lane only; one address per 16-lane row) and the taps
-        rh[j] = t0 > 0 ? *reinterpret_cast<const float4*>(xg + static_cast<size_t>(d) * L + t0 - 4)
-                       : make_float4(0.f, 0.f, 0.f, 0.f);
-        rt[j] = *reinterpret_cast<const float4*>(p.cw + static_cast<size_t>(d) * 4);
-        rb[j] = p.cb ? p.cb[d] : 0.f;
-      }
-      const int s = ws + 32 * j;
-      rw[j] = s < S ? *reinterpret_cast<const float4*>(p.wx + static_cast<size_t>(s) * D + k0 + wd)
-                    : make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int i = tid; i < 24 * kTok; i += kXdtThreads) sDt[i] = 0.f;   // rows >= R stay zero
+  if (kConv) {
+    for (int d = tid; d < D; d += kXdtThreads) {
+      *reinterpret_cast<float4*>(&sTap[4 * d]) = *reinterpret_cast<const float4*>(p.cw + 4 * static_cast<size_t>(d));
+      sBias[d] = p.cb ? p.cb[d] : 0.f;
     }
-  };
-  auto lstore = [&](int buf, int k0) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      float4 v = rx[j];
-      if (kConv) {
-        // previous pack of the row: the neighbouring lane's current pack (lane16 == 0: the halo load)
-        // The three DPP reads run with EVERY lane active and are pinned in front of the select: a DPP read of a lane
-        // that is masked off returns the `old` operand, and hipcc, left alone, predicates the false arm of a ternary
-        // (lane 1 of every row then read zeros from the masked-off lane 0: t0 + 4 .. 6 of every tile came out wrong).
-        const bool first = (tid & 15) == 0;
-        float q1 = dpp<DPP_ROW_SHR + 1>(0.f, rx[j].y);
-        float q2 = dpp<DPP_ROW_SHR + 1>(0.f, rx[j].z);
-        float q3 = dpp<DPP_ROW_SHR + 1>(0.f, rx[j].w);
-        asm volatile("" : "+v"(q1), "+v"(q2), "+v"(q3));
-        const float p1 = first ? rh[j].y : q1;
-        const float p2 = first ? rh[j].z : q2;
-        const float p3 = first ? rh[j].w : q3;
-        const float win[7] = {p1, p2, p3, rx[j].x, rx[j].y, rx[j].z, rx[j].w};
-        const float w4[4] = {rt[j].x, rt[j].y, rt[j].z, rt[j].w};
-        float o[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          float acc = rb[j];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) acc = fmaf(w4[q], win[i + q], acc);
-          o[i] = acc * sigmoid_f(acc);
-        }
-        v = make_float4(o[0], o[1], o[2], o[3]);
-        if (xok)
-          *reinterpret_cast<float4*>(p.xconv + (static_cast<size_t>(b) * D + k0 + xd + 16 * j) * L + t0 + xt) = v;
-        if (!xok) v = make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-      *reinterpret_cast<float4*>(&sX[buf][(xd + 16 * j) * kTok + xt]) = v;
-      *reinterpret_cast<float4*>(&sW[buf][(ws + 32 * j) * kWP + wd]) = rw[j];
-    }
-  };
-
-  // ---- phase 1 --------------------------------------------------------------------------------------------------
-  // Double-buffered LDS tiles, the next step's global loads in flight under this step's 16 MFMAs, one barrier per
-  // step.  (A register-level pipeline that also reads the next step's operands under the MFMAs and keeps three
-  // steps of global loads in flight measured no faster, 127 us against 120 us: three co-resident workgroups per CU
-  // already cover those latencies.)
-  f32x16 acc;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-  const int nk = D / kKS;
-  gload(0);
-  lstore(0, 0);
-  __syncthreads();
-  for (int ks = 0; ks < nk; ++ks) {
-    const int buf = ks & 1;
-    if (ks + 1 < nk) gload((ks + 1) * kKS);
-    const float* aw = &sW[buf][(sblk * 32 + li) * kWP + 16 * hh];
-    const float* bx = &sX[buf][(16 * hh) * kTok + tblk * 32 + li];
-    float av[16], bv[16];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float4 v = *reinterpret_cast<const float4*>(aw + 4 * q);
-      av[4 * q] = v.x; av[4 * q + 1] = v.y; av[4 * q + 2] = v.z; av[4 * q + 3] = v.w;
-    }
-#pragma unroll
-    for (int m = 0; m < 16; ++m) bv[m] = bx[m * kTok];
-#pragma unroll
-    for (int m = 0; m < 16; ++m) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bv[m], acc, 0, 0, 0);
-    if (ks + 1 < nk) lstore(buf ^ 1, (ks + 1) * kKS);
     __syncthreads();
   }
 
-  // ---- x_dbl out (token-major) and the dt rows into LDS ----------------------------------------------------------
-  // accumulator register r holds Y[s = sblk*32 + (r & 3) + 8 (r >> 2) + 4 hh][t = tblk*32 + li]
-  float* sDt = &sX[0][0];                                  // [R <= 32][64 t]; the phase-1 tiles are dead
-  {
-    const int t = t0 + tblk * 32 + li;
-    float* row = p.xdbl + (static_cast<size_t>(b) * L + t) * S;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int s = sblk * 32 + 8 * g + 4 * hh;
-      if (t < L && s < S)                                  // S % 4 == 0: four states are all in or all out
-        *reinterpret_cast<float4*>(row + s) = make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
-      if (sblk == 0) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int r = 8 * g + 4 * hh + i;
-          if (r < R) sDt[r * kTok + tblk * 32 + li] = acc[4 * g + i];
-        }
-      }
-    }
-  }
-  __syncthreads();
+  auto advance = [&](Cursor& c, int n) {                   // n <= nk steps forward
+    c.ks += n;
+    const bool wrap = c.ks >= nk;
+    c.ks -= wrap ? nk : 0;
+    c.j += wrap ? 1 : 0;
+    c.r += wrap ? gr : 0;
+    c.q += wrap ? gq : 0;
+    const bool carry = c.r >= tps;
+    c.r -= carry ? tps : 0;
+    c.q += carry ? 1 : 0;
+  };
 
-  // ---- phase 2: delta = Wdt @ dt --------------------------------------------------------------------------------
+  // ---- staging identities ---------------------------------------------------------------------------------------
+  // x tile: 32 d x 64 t = 512 float4; thread -> (d = tid >> 4 (+16), t4 = 4 (tid & 15)); byte offsets inside a sample
+  const int xd = tid >> 4, xt = 4 * (tid & 15);
+  const bool first = (tid & 15) == 0;                     // first pack of its tile row
+  unsigned xoff[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) xoff[i] = (static_cast<unsigned>(xd + 16 * i) * L + xt) * 4u;
+  // Wx tile: 64 s x 32 d = 512 float4; thread -> (s = tid >> 3 (+32), d4 = 4 (tid & 7)); rows >= S are out of range
+  const int ws = tid >> 3, wd = 4 * (tid & 7);
+  unsigned woff[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) woff[i] = (ws + 32 * i < S) ? (static_cast<unsigned>(ws + 32 * i) * D + wd) * 4u : kOob;
+  const rsrc_t rs_wx = make_rsrc(p.wx, static_cast<unsigned>(S) * D * 4u);
+  const rsrc_t rs_wdt = make_rsrc(p.wdt, static_cast<unsigned>(D) * R * 4u);
+
+  struct Stage { float4 rx[2], rw[2], rh[2]; };
+  struct Ops { float a[16], b[16]; };
+
+  // global loads of a step (zeros past the tile's end, past row S, and for a step past the last tile)
+  auto issue = [&](Stage& st, const Cursor& c) {
+    const rsrc_t rs = make_rsrc(p.x + static_cast<size_t>(c.q) * p.x_bs, c.j < ntw ? sample_bytes : 0u);
+    const int t0 = c.r * kTok;
+    const unsigned soff = (static_cast<unsigned>(c.ks) * kKS * L + t0) * 4u;
+    const bool xok = t0 + xt < L;                          // L % 4 == 0: a pack is all in or all out
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      st.rx[i] = bload4(rs, xok ? xoff[i] : kOob, soff);
+      // the pack in front of the tile, for the row's first lane only (t0 = 0: nothing in front -- zeros)
+      // (the 16 bytes back go into the scalar offset: t0 > 0 makes soff >= 256, while xoff - 16 would wrap for d = 0)
+      if (kConv) st.rh[i] = bload4(rs, (first && t0 > 0) ? xoff[i] : kOob, soff - 16u);
+      st.rw[i] = bload4(rs_wx, woff[i], static_cast<unsigned>(c.ks) * kKS * 4u);
+    }
+  };
+  // conv + SiLU (kConv), x_conv out, LDS tiles of the step
+  auto stage = [&](const Stage& st, const Cursor& c, int buf) {
+    rsrc_t rs_xc;
+    unsigned soff = 0;
+    bool xok = true;
+    if (kConv) {
+      rs_xc = make_rsrc(p.xconv + static_cast<size_t>(c.q) * D * L, c.j < ntw ? sample_bytes : 0u);
+      const int t0 = c.r * kTok;
+      soff = (static_cast<unsigned>(c.ks) * kKS * L + t0) * 4u;
+      xok = t0 + xt < L;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      float4 v = st.rx[i];
+      if (kConv) {
+        const int d = c.ks * kKS + xd + 16 * i;
+        // previous pack of the row: the neighbouring lane's current pack (row's first lane: the halo load).
+        // The three DPP reads run with EVERY lane active and are pinned in front of the select: a DPP read of a lane
+        // that is masked off returns the `old` operand, and hipcc, left alone, predicates the false arm of a ternary.
+        float q1 = dpp<DPP_ROW_SHR + 1>(0.f, v.y);
+        float q2 = dpp<DPP_ROW_SHR + 1>(0.f, v.z);
+        float q3 = dpp<DPP_ROW_SHR + 1>(0.f, v.w);
+        asm volatile("" : "+v"(q1), "+v"(q2), "+v"(q3));
+        const float p1 = first ? st.rh[i].y : q1;
+        const float p2 = first ? st.rh[i].z : q2;
+        const float p3 = first ? st.rh[i].w : q3;
+        const float win[7] = {p1, p2, p3, v.x, v.y, v.z, v.w};
+        const float4 tp = *reinterpret_cast<const float4*>(&sTap[4 * d]);
+        const float w4[4] = {tp.x, tp.y, tp.z, tp.w};
+        const float bias = sBias[d];
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float acc = bias;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc = fmaf(w4[q], win[e + q], acc);
+          o[e] = acc * sigmoid_f(acc);
+        }
+        v = make_float4(o[0], o[1], o[2], o[3]);
+        bstore4(v, rs_xc, xok ? xoff[i] : kOob, soff);
+        if (!xok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      *reinterpret_cast<float4*>(&sX[buf][(xd + 16 * i) * kTok + xt]) = v;
+      *reinterpret_cast<float4*>(&sW[buf][(ws + 32 * i) * kWP + wd]) = st.rw[i];
+    }
+  };
+  // operands of a step: A = 64 contiguous bytes of a Wx row per lane, B = one column of the x tile
+  auto read_ops = [&](Ops& o, int buf) {
+    const float* aw = &sW[buf][(sblk * 32 + li) * kWP + 16 * hh];
+    const float* bx = &sX[buf][(16 * hh) * kTok + tblk * 32 + li];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 v = *reinterpret_cast<const float4*>(aw + 4 * q);
+      o.a[4 * q] = v.x; o.a[4 * q + 1] = v.y; o.a[4 * q + 2] = v.z; o.a[4 * q + 3] = v.w;
+    }
+#pragma unroll
+    for (int m = 0; m < 16; ++m) o.b[m] = bx[m * kTok];
+  };
+
+  // ---- delta = Wdt @ dt of a finished tile, one (d-block, token block) unit at a time ------------------------------
   // B operands: MFMA m contracts r = (m & 3) + 8 (m >> 2) + 4 hh; rows >= R contribute zeros.  A wave keeps the dt
   // rows of both 32-token blocks in registers and takes the d-blocks w, w + 4, ...: every Wdt row is loaded once per
-  // workgroup.  (Measured against giving a wave one token block and twice the d-blocks -- 90 VGPRs, four workgroups
-  // per CU instead of three: 133 us instead of 120 us at (64, 768, 1024).)
+  // workgroup and tile.  The accumulator's C/D layout puts a store instruction on two rows x 128 contiguous bytes.
+  // A unit past the wave's last one addresses d-block >= ndb: its Wdt loads and delta stores fall out of range.
   constexpr int kM2 = 12;                                  // R <= 24
-  float bdt[2][kM2];
+  float4 wa[3];
+  unsigned wdoff[3];
 #pragma unroll
-  for (int tb = 0; tb < 2; ++tb)
+  for (int g = 0; g < 3; ++g) wdoff[g] = (8 * g + 4 * hh < R) ? (static_cast<unsigned>(li) * R + 4 * hh + 8 * g) * 4u : kOob;
+  const unsigned dvoff = (static_cast<unsigned>(4 * hh) * L + li) * 4u;   // delta: row 4 hh, column li of a 32 x 32 block
+  auto wload = [&](int u) {                                // the Wdt rows of unit u (and u + 1: same d-block)
+    const int db = wave + 4 * (u >> 1);
+    const unsigned soff = db < ndb ? static_cast<unsigned>(db) * 32u * R * 4u : 0u;
 #pragma unroll
-    for (int m = 0; m < kM2; ++m) {
-      const int r = (m & 3) + 8 * (m >> 2) + 4 * hh;
-      bdt[tb][m] = r < R ? sDt[r * kTok + tb * 32 + li] : 0.f;
-    }
-  const int ndb = D / 32;                                  // d-blocks of 32 channels; wave w takes w, w + 4, ...
-  float4 wa[3], wn[3];
-  auto wload = [&](int db, float4 (&dst)[3]) {
-    const float* row = p.wdt + static_cast<size_t>(db * 32 + li) * R + 4 * hh;
-#pragma unroll
-    for (int g = 0; g < 3; ++g)
-      dst[g] = (8 * g + 4 * hh < R) ? *reinterpret_cast<const float4*>(row + 8 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int g = 0; g < 3; ++g) wa[g] = bload4(rs_wdt, db < ndb ? wdoff[g] : kOob, soff);
   };
-  if (wave < ndb) wload(wave, wa);
-  for (int db = wave; db < ndb; db += 4) {
-    if (db + 4 < ndb) wload(db + 4, wn);
+  // the dt rows of the unit's token block come from LDS (rows >= R: lanes read row 0 and contribute zeros)
+  const int dtoff = 4 * hh * kTok + li;
+  auto unit_mfma = [&](int u, f32x16& o) {
     const float a2[kM2] = {wa[0].x, wa[0].y, wa[0].z, wa[0].w, wa[1].x, wa[1].y, wa[1].z, wa[1].w,
                            wa[2].x, wa[2].y, wa[2].z, wa[2].w};
+    const float* dt = &sDt[dtoff + (u & 1) * 32];
+    float b2[kM2];
 #pragma unroll
-    for (int tb = 0; tb < 2; ++tb) {
-      f32x16 o;
+    for (int m = 0; m < kM2; ++m) b2[m] = dt[((m & 3) + 8 * (m >> 2)) * kTok];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) o[i] = 0.f;
+    for (int i = 0; i < 16; ++i) o[i] = 0.f;
 #pragma unroll
-      for (int m = 0; m < kM2; ++m) o = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[m], bdt[tb][m], o, 0, 0, 0);
-      const int t = t0 + tb * 32 + li;
-      if (t < L) {
-        float* dst = p.delta + (static_cast<size_t>(b) * D + db * 32 + 4 * hh) * L + t;
+    for (int m = 0; m < kM2; ++m) o = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[m], b2[m], o, 0, 0, 0);
+  };
+  auto unit_store = [&](int u, const f32x16& o, int q, int r) {   // tile (sample q, tile r of it)
+    const int db = wave + 4 * (u >> 1);
+    const rsrc_t rs = make_rsrc(p.delta + static_cast<size_t>(q) * D * L, db < ndb ? sample_bytes : 0u);
+    const int tb0 = r * kTok + (u & 1) * 32;
+    const unsigned voff = tb0 + li < L ? dvoff : kOob;
+    const unsigned base = (static_cast<unsigned>(db) * 32u * L + tb0) * 4u;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dst[static_cast<size_t>((r & 3) + 8 * (r >> 2)) * L] = o[r];
-      }
-    }
+    for (int i = 0; i < 16; ++i) bstore1(o[i], rs, voff, base + static_cast<unsigned>((i & 3) + 8 * (i >> 2)) * L * 4u);
+  };
+
+  // ---- the pipeline ----------------------------------------------------------------------------------------------
+  f32x16 acc;
 #pragma unroll
-    for (int g = 0; g < 3; ++g) wa[g] = wn[g];
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  Stage s0, s1;
+  Ops o0;
+  const int q0 = wg / tps;
+  Cursor cm{0, 0, q0, wg - q0 * tps};                     // step g            (MFMAs)
+  Cursor cr = cm, cs = cm, cl = cm;
+  advance(cr, 1);                                          // step g + 1        (operand reads)
+  advance(cs, 1); advance(cs, 1);                          // step g + 2        (conv + LDS store)
+  {
+    // prologue: steps 0 and 1 staged, 2 and 3 in flight, operands of step 0 in registers
+    issue(s0, cm);
+    issue(s1, cr);
+    stage(s0, cm, 0);
+    issue(s0, cs);
+    stage(s1, cr, 1);
+    cl = cs; advance(cl, 1);
+    issue(s1, cl);
+    advance(cl, 1);                                        // step g + 4        (global loads)
+    __syncthreads();
+    read_ops(o0, 0);
+    __syncthreads();                                       // buffer 0 is restaged in iteration 0
   }
-  __syncthreads();                                         // sDt (= the first x tile buffer) is refilled by the next tile
+  int pq = 0, pr = 0;                                      // the previous tile (delta units)
+  // One iteration; kOdd: the odd step of a pair (delta unit ks >> 1 of the previous tile when kUnits).
+  auto iteration = [&](Ops& cur, Stage& st, const int buf, auto odd_tag, auto units_tag) {
+    constexpr bool kOdd = decltype(odd_tag)::value, kUnits = decltype(units_tag)::value;
+    f32x16 o;
+    const int u = cm.ks >> 1;
+    if (kOdd && kUnits) unit_mfma(u, o);
+#pragma unroll
+    for (int m = 0; m < 16; ++m) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[m], cur.b[m], acc, 0, 0, 0);
+    stage(st, cs, buf);
+    if (kOdd && kUnits) {
+      unit_store(u, o, pq, pr);
+      wload(u + 1);
+    }
+    issue(st, cl);
+    read_ops(cur, buf ^ 1);                                // step g + 1, once the MFMAs above have taken step g's
+    advance(cm, 1); advance(cr, 1); advance(cs, 1); advance(cl, 1);
+    __syncthreads();
+  };
+  using T = std::true_type;
+  using F = std::false_type;
+  for (int j = 0; j < ntw; ++j) {
+    if (j == 0) {
+      for (int k = 0; k < nk; k += 2) {                    // nk is even: a tile starts on an even step
+        iteration(o0, s0, 0, F{}, F{});
+        iteration(o0, s1, 1, T{}, F{});
+      }
+    } else {
+      wload(0);
+      for (int k = 0; k < nk; k += 2) {
+        iteration(o0, s0, 0, F{}, T{});
+        iteration(o0, s1, 1, T{}, T{});
+      }
+      for (int u = nk / 2; u < nunits; ++u) {              // ndb % 4 != 0: units past nk / 2 (none at D = 768)
+        f32x16 o;
+        if (!(u & 1)) wload(u);
+        unit_mfma(u, o);
+        unit_store(u, o, pq, pr);
+      }
+      // those units read the previous tile's dt rows, which the waves that have none are about to overwrite below
+      if (2 * ((ndb + 3) / 4) > nk / 2) __syncthreads();
+    }
+    // ---- the tile is complete: x_dbl out (token-major), its dt rows into LDS, accumulator cleared ---------------------
+    // accumulator register r holds Y[s = sblk*32 + (r & 3) + 8 (r >> 2) + 4 hh][t = tblk*32 + li]
+    {
+      const int tile = wg + j * nwg;
+      const int b = tile / tps, t0 = (tile - b * tps) * kTok;
+      pq = b; pr = tile - b * tps;
+      const int t = t0 + tblk * 32 + li;
+      float* row = p.xdbl + (static_cast<size_t>(b) * L + t) * S;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int s = sblk * 32 + 8 * g + 4 * hh;
+        if (t < L && s < S)                                // S % 4 == 0: four states are all in or all out
+          *reinterpret_cast<float4*>(row + s) = make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
+        if (sblk == 0) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int r = 8 * g + 4 * hh + i;
+            if (r < R) sDt[r * kTok + tblk * 32 + li] = acc[4 * g + i];
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    }
+    __syncthreads();
+  }
+
+  // ---- tail: delta of the last tile --------------------------------------------------------------------------------
+  for (int u = 0; u < nunits; ++u) {
+    f32x16 o;
+    if (!(u & 1)) wload(u);
+    unit_mfma(u, o);
+    unit_store(u, o, pq, pr);
   }
 }
 
@@ -244,7 +392,9 @@ static int xdt_launch(const void* x, const float* cw, const float* cb, const flo
                       long long x_bstride, bool conv, void* stream) {
   if (batch < 0 || D <= 0 || L < 0 || batch > 65535) return SIMAMBA_E_SHAPE;
   if (io_dtype != SIMAMBA_F32) return SIMAMBA_E_DTYPE;
-  if (D % 32 || L % 4 || S % 4 || S > kSPad || S < R || R % 4 || R > 24 || R < 4) return SIMAMBA_E_SHAPE;
+  if (D % 64 || L % 4 || S % 4 || S > kSPad || S < R || R % 4 || R > 24 || R < 4) return SIMAMBA_E_SHAPE;
+  if (conv && D > kMaxDConv) return SIMAMBA_E_SHAPE;
+  if (static_cast<long long>(D) * L * 4 >= (1LL << 32) - 65536 || static_cast<long long>(S) * D * 4 >= (1LL << 31)) return SIMAMBA_E_SHAPE;
   if (batch == 0 || L == 0) return SIMAMBA_OK;
   if (!x || !wx || !wdt || !xdbl || !delta || (conv && (!cw || !xconv))) return SIMAMBA_E_NULLPTR;
   uintptr_t al = reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(wx) | reinterpret_cast<uintptr_t>(wdt) |
@@ -258,11 +408,12 @@ static int xdt_launch(const void* x, const float* cw, const float* cb, const flo
   a.batch = batch; a.D = D; a.L = L; a.S = S; a.R = R;
   a.x_bs = x_bstride ? x_bstride : static_cast<long long>(D) * L;
   if (a.x_bs % 4) return SIMAMBA_E_ALIGN;
-  // grid: every workgroup the same number of tiles, all workgroups resident together (3 fit per CU, 256 CUs)
+  // grid: every workgroup the same number of tiles, all workgroups resident together (2 per CU, 256 CUs)
   const long long ntiles = static_cast<long long>(batch) * ((L + kTok - 1) / kTok);
+  if (ntiles > 0x7fffffffLL) return SIMAMBA_E_SHAPE;
   long long g = ntiles;
-  if (ntiles > 768) {
-    long long per = (ntiles + 767) / 768;                  // tiles per workgroup at full residency
+  if (ntiles > 512) {
+    long long per = (ntiles + 511) / 512;                  // tiles per workgroup at full residency
     while (ntiles % per) ++per;                            // ... evened out (per divides ntiles)
     g = ntiles / per;
   }
@@ -274,7 +425,7 @@ static int xdt_launch(const void* x, const float* cw, const float* cb, const flo
   return static_cast<int>(hipGetLastError());
 }
 
-// fp32 only (bf16 mixers keep the library GEMMs); D % 32 == 0, L % 4 == 0, S % 4 == 0, S <= 64, R % 4 == 0, R <= 24.
+// fp32 only (bf16 mixers keep the library GEMMs); D % 64 == 0, L % 4 == 0, S % 4 == 0, S <= 64, R % 4 == 0, R <= 24.
 extern "C" int simamba_xdt_proj_fwd(const void* x, const float* wx, const float* wdt, void* xdbl, void* delta,
                                     int batch, int D, int L, int S, int R, int io_dtype, long long x_bstride,
                                     void* stream) {

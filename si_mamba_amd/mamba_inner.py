@@ -78,14 +78,15 @@ def in_proj_fn(hidden, weight, bias=None):
     return InProjFn.apply(hidden, weight, bias)
 
 
-def xdt_proj_fused_ok(x, wx, wdt):
+def xdt_proj_fused_ok(x, wx, wdt, conv=False):
     """Shapes / dtypes the hand-written MFMA kernel takes (include/simamba.h); anything else runs the two library
-    GEMMs."""
+    GEMMs (and, with ``conv``, the separate conv kernel)."""
     S, D = wx.shape
     R = wdt.shape[1]
     return (x.is_cuda and x.dtype == torch.float32 and wx.dtype == torch.float32 and wdt.dtype == torch.float32
             and x.dim() == 3 and x.stride(2) == 1 and x.stride(1) == x.shape[2] and x.stride(0) % 4 == 0
-            and x.shape[1] == D and D % 32 == 0 and x.shape[2] % 4 == 0 and S % 4 == 0 and S <= 64
+            and x.shape[1] == D and D % 64 == 0 and x.shape[2] % 4 == 0 and S % 4 == 0 and S <= 64
+            and D * x.shape[2] * 4 < 2 ** 32 - 65536 and (not conv or D <= 1024)
             and R % 4 == 0 and 4 <= R <= 24 and S >= R and wdt.shape[0] == D and x.data_ptr() % 16 == 0)
 
 
@@ -143,7 +144,7 @@ class MambaInnerFn(torch.autograd.Function):
         xw_c, dtw_c, ow_c = _w(x_proj_w, io), _w(dt_proj_w, io), _w(out_proj_w, io)   # compute-dtype weights,
         ctx.wcast = (xw_c, dtw_c, ow_c)                                               # reused by backward
         x_conv = torch.empty(Bsz, Dm, L, device=dev, dtype=io)
-        if W == 4 and xdt_proj_fused_ok(x_in, xw_c, dtw_c):
+        if W == 4 and xdt_proj_fused_ok(x_in, xw_c, dtw_c, conv=True):
             # conv1d + SiLU -> x_proj -> dt_proj as ONE pass over the x half of xz on the matrix cores
             # (csrc/xdt_proj.hip); x_conv is written as a by-product for the scan and the backward
             x_dbl, delta = xdt_proj_fwd(x_in, xw_c, dtw_c, conv=(cw, cb, x_conv))

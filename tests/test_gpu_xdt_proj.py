@@ -12,8 +12,11 @@ def nerr(got, want):
     return ((got - want).abs().max() / max(1.0, want.abs().max().item())).item()
 
 
+# the last three walk several tiles per workgroup (> 512 tiles): D = 64 has two steps per tile (the four-step lookahead
+# crosses two tile seams), D = 192 leaves a wave delta blocks past the in-loop slots, L = 616 has a ragged last tile
 @pytest.mark.parametrize("B,D,L,N,R", [(2, 768, 1024, 16, 24), (3, 256, 64, 16, 8), (1, 768, 208, 16, 24),
-                                       (2, 128, 36, 16, 8), (64, 768, 1024, 16, 24), (1, 64, 4, 16, 4)])
+                                       (2, 128, 36, 16, 8), (64, 768, 1024, 16, 24), (1, 64, 4, 16, 4),
+                                       (40, 64, 1024, 16, 4), (60, 192, 640, 16, 12), (130, 128, 616, 16, 8)])
 def test_xdt_proj_matches_float64_products(B, D, L, N, R, device):
     from si_mamba_amd.mamba_inner import xdt_proj_fused_ok, xdt_proj_fwd
     S = R + 2 * N
@@ -61,7 +64,7 @@ def test_mixer_uses_the_fused_kernel_and_matches_the_library_route(device, monke
     g1 = {k: p.grad.clone() for k, p in m.named_parameters()}
     assert calls and calls[0].get("conv") is not None, "fp32 mixer forward did not take the fused conv + x_proj + dt_proj kernel"
     m.zero_grad(set_to_none=True)
-    monkeypatch.setattr(mamba_inner, "xdt_proj_fused_ok", lambda *a: False)
+    monkeypatch.setattr(mamba_inner, "xdt_proj_fused_ok", lambda *a, **k: False)
     h2 = h.clone().requires_grad_(True)
     o2 = m(h2)
     o2.sum().backward()
@@ -70,7 +73,8 @@ def test_mixer_uses_the_fused_kernel_and_matches_the_library_route(device, monke
         assert nerr(g1[k], p.grad) < 1e-4, k
 
 
-@pytest.mark.parametrize("B,D,L", [(2, 768, 1024), (3, 256, 68), (1, 64, 4), (64, 768, 1024)])
+@pytest.mark.parametrize("B,D,L", [(2, 768, 1024), (3, 256, 68), (1, 64, 4), (64, 768, 1024), (40, 64, 1024),
+                                   (60, 192, 616)])
 @pytest.mark.parametrize("bias", [True, False])
 def test_conv_fused_into_the_staging_matches_the_conv_kernel(B, D, L, bias, device):
     """simamba_conv_xdt_proj_fwd: the conv output written as a by-product equals the stand-alone conv kernel's bit for
