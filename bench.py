@@ -172,6 +172,9 @@ def main():
     ap.add_argument("--npoints", type=int, default=1024)
     ap.add_argument("--groups", type=int, default=128)
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32")
+    ap.add_argument("--scan-variant", type=int, default=0,
+                    help="A/B tool: force one forward-scan kernel (include/simamba.h SIMAMBA_SCAN_*; 0 = the library's "
+                         "choice, which is what every reported line uses)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-headline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -232,6 +235,7 @@ def main():
     for _ in range(args.warmup):
         step()
     _lib.enable_kernel_timing(not args.no_kernel_timing)
+    _lib._scan_variant[0] = args.scan_variant
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -270,8 +274,12 @@ def main():
             nbytes = scan_fwd_bytes(args.batch, D, L, N, s)
             ach = nbytes / ms / 1e6
             rows = args.batch * D
-            fwd_kernel = (f"scan_fwd_seq_kernel<{'float' if s == 4 else 'bf16'},true,2>" if rows >= 48 * 1024 else
-                          f"scan_fwd_kernel<{'float' if s == 4 else 'bf16'},{16 if L >= 768 else 8}>")
+            tname = "float" if s == 4 else "bf16"
+            auto = _lib.load().simamba_scan_fwd_auto_variant(args.batch, D)        # the library's own choice
+            fwd_kernel = {_lib.SCAN_MIX: f"scan_fwd_seq_mix_kernel<{tname},true>",
+                          _lib.SCAN_LPC2: f"scan_fwd_seq_kernel<{tname},true,2>",
+                          _lib.SCAN_LPC4: f"scan_fwd_seq_kernel<{tname},true,4>"}.get(
+                              auto, f"scan_fwd_kernel<{tname},{16 if L >= 768 else 8}>")
             out["roofline"] = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(ach / HBM_PEAK_GBS, 4),
                                "traffic": traffic_from_profiles("scan_fwd", (args.batch, D, L, N)) if s == 4 else None,
@@ -281,7 +289,9 @@ def main():
                                "note": "VALU-bound on CDNA4, not HBM-bound (DESIGN.md 4.1): 5 VALU per (row, step, "
                                        "state) incl. one quarter-rate v_exp_f32 and two DPP operands; PMC: VALU "
                                        ">90 % busy, HBM traffic 1.0x algorithmic. At this shape 1536 waves on 1024 "
-                                       "SIMDs: half of the SIMDs carry two waves"}
+                                       "SIMDs: half of the SIMDs carry two waves (the mixed 2 + 4 lanes launch that "
+                                       "evens them out is 14 % faster alone, 15 % slower behind the 400 MB the "
+                                       "preceding kernel has just written: DESIGN.md 4.1)"}
             out["kernels"] = {k: {"launches": v[0], "mean_ms": round(v[1], 4)} for k, v in ktimes.items()}
             if "scan_bwd" in ktimes:
                 bb = scan_bwd_bytes(args.batch, D, L, N, s)

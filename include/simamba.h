@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define SIMAMBA_ABI_VERSION 6
+#define SIMAMBA_ABI_VERSION 7
 
 #define SIMAMBA_F32  0
 #define SIMAMBA_BF16 1
@@ -69,6 +69,9 @@ extern "C" {
 int         simamba_abi_version(void);
 const char* simamba_strerror(int rc);           /* host string, static storage */
 int         simamba_scan_num_chunks(int seqlen);
+/* the forward kernel SIMAMBA_SCAN_AUTO picks for (batch, dim) when the operands qualify for all of them (one of the
+ * SIMAMBA_SCAN_* values below; host-side arithmetic only, no GPU work): what a profile's kernel name should be */
+int         simamba_scan_fwd_auto_variant(int batch, int dim);
 
 /*
  * Selective scan forward.
@@ -85,13 +88,17 @@ int         simamba_scan_num_chunks(int seqlen);
  *                      environment variables, no global state).  The explicit values select one kernel for
  *                      benchmarks and parity tests: ROWSCAN (16 lanes per row, any shape), LPC2 / LPC4 (2 / 4
  *                      lanes per channel, 32-step chunks; need dstate == 16, 16-byte aligned rows and tensors
- *                      below 2^30 elements, else SIMAMBA_E_VARIANT).  All variants compute the same function.
+ *                      below 2^30 elements, else SIMAMBA_E_VARIANT), MIX (one launch with the first channels of
+ *                      every sample on 2 and the last ones on 4 lanes per channel, for shapes whose 2-lane launch
+ *                      leaves at most half a round of waves over, e.g. batch * dim = 49 152; else SIMAMBA_E_VARIANT).
+ *                      All variants compute the same function.
  *   out = (scan(u, softplus?(delta + delta_bias), A, B, C) + D*u) * silu(z)
  */
 #define SIMAMBA_SCAN_AUTO    0
 #define SIMAMBA_SCAN_ROWSCAN 1
 #define SIMAMBA_SCAN_LPC2    2
 #define SIMAMBA_SCAN_LPC4    4
+#define SIMAMBA_SCAN_MIX     6
 int simamba_selective_scan_fwd(const void* u, const void* delta, const float* A,
                                const void* B, const void* C, const float* D, const void* z,
                                const float* delta_bias, void* out, float* x_ckpt,

@@ -23,16 +23,17 @@ SPEC_SMALLEST = 0x10
 SPEC_SIGMA_MEAN = 0x20
 
 # forward-scan kernel selection (include/simamba.h): AUTO in production, the others for benchmarks / parity tests
-SCAN_AUTO, SCAN_ROWSCAN, SCAN_LPC2, SCAN_LPC4 = 0, 1, 2, 4
+SCAN_AUTO, SCAN_ROWSCAN, SCAN_LPC2, SCAN_LPC4, SCAN_MIX = 0, 1, 2, 4, 6
 
 # name -> (restype, argtypes); mirrors include/simamba.h one to one
 _P = c_void_p
 _LL = c_longlong
-ABI_VERSION = 6
+ABI_VERSION = 7
 SIGNATURES = {
     "simamba_abi_version": (c_int, []),
     "simamba_strerror": (c_char_p, [c_int]),
     "simamba_scan_num_chunks": (c_int, [c_int]),
+    "simamba_scan_fwd_auto_variant": (c_int, [c_int, c_int]),
     "simamba_selective_scan_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                            c_int, c_int, c_int, c_int, c_int, c_int,
                                            _LL, _LL, _LL, _LL, c_int, _P]),

@@ -52,6 +52,7 @@ struct SeqArgs {
   float* last_state;
   int batch, dim, seqlen, nchunks128;
   int bc_mode;                             // 1 time-major packs of B / C, 2 token-major packs
+  int mix_c4;                              // mixed launch: the last mix_c4 channels of a sample run four lanes per channel
   long long z_bs;
   long long bc_bs, bc_ns, bc_ts;
 };
@@ -121,19 +122,13 @@ template <int kLPC> struct SeqCfg {
   static constexpr int kWaves = kLPC == 2 ? 3 : 4;
 };
 
+// One wave's work: channels ch_base .. ch_base + R of sample b, the whole sequence.  tD: the wave's LDS tiles.
 template <typename T, bool kHasZ, int kLPC>
-__global__ __launch_bounds__(kSeqThreads, SeqCfg<kLPC>::kWaves) void scan_fwd_seq_kernel(SeqArgs p) {
+__device__ __forceinline__ void seq_body(const SeqArgs& p, const int b, const int ch_base, float* tD) {
   typedef SeqCfg<kLPC> Cfg;
   constexpr int NS = Cfg::NS, R = Cfg::R, kPacks = Cfg::kPacks;
-  __shared__ __attribute__((aligned(16))) float sMem[kSeqThreads / 64][Cfg::kTileFloats];
-  int tile_id, b;
-  xcd_tile(tile_id, b);
-  const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);   // SGPR
   const int lane = threadIdx.x & 63;
   const int L = p.seqlen, D = p.dim;
-  const int ch_base = (tile_id * (kSeqThreads / 64) + wave) * R;   // first channel of this wave
-  if (ch_base >= D) return;                                            // whole wave idle (no barriers here)
-  float* tD = &sMem[wave][0];
   float* tU = tD + R * kSeqTC;
   float* tBC = tU + R * kSeqTC;            // [32 steps][B_t(16) | C_t(16) | pad(4)]
 
@@ -358,6 +353,48 @@ __global__ __launch_bounds__(kSeqThreads, SeqCfg<kLPC>::kWaves) void scan_fwd_se
   }
 }
 
+template <typename T, bool kHasZ, int kLPC>
+__global__ __launch_bounds__(kSeqThreads, SeqCfg<kLPC>::kWaves) void scan_fwd_seq_kernel(SeqArgs p) {
+  typedef SeqCfg<kLPC> Cfg;
+  __shared__ __attribute__((aligned(16))) float sMem[kSeqThreads / 64][Cfg::kTileFloats];
+  int tile_id, b;
+  xcd_tile(tile_id, b);
+  const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);   // SGPR
+  const int ch_base = (tile_id * (kSeqThreads / 64) + wave) * Cfg::R;  // first channel of this wave
+  if (ch_base >= p.dim) return;                                        // whole wave idle (no barriers here)
+  seq_body<T, kHasZ, kLPC>(p, b, ch_base, &sMem[wave][0]);
+}
+
+// Both forms in one launch of one-wave workgroups: the first dim - mix_c4 channels of every sample two lanes per
+// channel (32 channels a wave), the last mix_c4 four lanes per channel (16 a wave, 0.68 of the instructions).  At
+// (64, 768, 1024) two lanes per channel is 1536 waves on 1024 SIMDs -- half of the SIMDs carry two waves, the kernel
+// lasts two wave-times; with the last 256 channels of every sample on four lanes it is 1024 + 1024 waves, one of
+// each per SIMD: 1.68 wave-times.  Block order: an XCD receives ids x, x + 8, ...; it is handed its two-lane waves
+// first (one per SIMD while they last) and the four-lane ones after, and both parts of a sample stay on one XCD (they
+// share B_t / C_t in its L2).
+// Measured (tools/bench_scan_context.py, (64, 768, 1024) fp32): 245-254 us against 285 us for the two-lane launch when
+// the launch follows itself or a small GEMM -- but 340-347 us against 303 us right after a kernel that left 400 MB of
+// dirty lines in L2 / MALL, which is how the mixer calls it (conv + x_proj + dt_proj have just written x_conv and
+// delta): there the launch competes with that write-back for HBM and finishing the same bytes in less time is not
+// available.  Inside the model: 347 us against 302 us (rocprofv3).  So SIMAMBA_SCAN_AUTO does not pick it; it stays
+// an explicit variant with its parity tests.
+template <typename T, bool kHasZ>
+__global__ __launch_bounds__(64, SeqCfg<2>::kWaves) void scan_fwd_seq_mix_kernel(SeqArgs p) {
+  __shared__ __attribute__((aligned(16))) float sMem[SeqCfg<2>::kTileFloats];
+  const int g2 = (p.dim - p.mix_c4) / SeqCfg<2>::R, g4 = p.mix_c4 / SeqCfg<4>::R;   // waves per sample of each form
+  int x = 0, k = blockIdx.x, bx = p.batch;
+  if (p.batch % kNumXcd == 0) { x = k % kNumXcd; k /= kNumXcd; bx = p.batch / kNumXcd; }
+  const int n2 = bx * g2;
+  if (k < n2) {
+    const int sample = k / g2;
+    seq_body<T, kHasZ, 2>(p, x * bx + sample, (k - sample * g2) * SeqCfg<2>::R, sMem);
+  } else {
+    k -= n2;
+    const int sample = k / g4;
+    seq_body<T, kHasZ, 4>(p, x * bx + sample, p.dim - p.mix_c4 + (k - sample * g4) * SeqCfg<4>::R, sMem);
+  }
+}
+
 template <typename T, int kLPC>
 static void launch_seq_lpc(const SeqArgs& a, hipStream_t s) {
   const int ch_per_wg = (kSeqThreads / 64) * SeqCfg<kLPC>::R;
@@ -380,8 +417,25 @@ int scan_fwd_seq_bc_mode(const void* B, const void* C, int io_dtype, long long b
   return 0;
 }
 
+// Channels per sample to run four lanes per channel in the mixed launch, 0 when mixing does not help.  With two lanes
+// per channel the launch is n = rows / 32 waves on 1024 SIMDs: q full rounds and r left over.  0 < r <= 512: the
+// left-over waves' channels go four lanes per channel instead (2 r waves of 0.68 wave-times each, at most one per
+// SIMD) and the kernel lasts q + 0.68 wave-times instead of q + 1.  r > 512 has no such split (some SIMD would
+// carry a two-lane wave of the last round anyway).
+int scan_fwd_seq_mix_c4(int batch, int dim) {
+  constexpr long long kSimds = 1024;
+  if (kSeqThreads != 64 || dim % 32 || batch <= 0) return 0;
+  const long long n = static_cast<long long>(batch) * dim / 32;
+  const long long q = n / kSimds, r = n % kSimds;
+  if (r == 0 || r > kSimds / 2 || q + 1 > SeqCfg<2>::kWaves) return 0;
+  if ((32 * r) % batch) return 0;
+  const long long c4 = 32 * r / batch;
+  if (c4 % 32 || c4 > dim) return 0;
+  return static_cast<int>(c4);
+}
+
 // Entry used by simamba_selective_scan_fwd (scan_fwd.hip) when the shape qualifies (16 states, softplus on,
-// pack-aligned rows and B / C, 32-bit byte offsets); lpc = 2 or 4.
+// pack-aligned rows and B / C, 32-bit byte offsets); lpc = 2 or 4, or 6 = the mixed launch (scan_fwd_seq_mix_c4 != 0).
 int scan_fwd_seq_dispatch(const void* u, const void* delta, const float* A, const void* B, const void* C, const float* D,
                           const void* z, const float* delta_bias, void* out, float* x_ckpt, float* last_state,
                           int batch, int dim, int seqlen, int io_dtype, long long z_bs,
@@ -395,6 +449,19 @@ int scan_fwd_seq_dispatch(const void* u, const void* delta, const float* A, cons
   a.bc_bs = bc_bs; a.bc_ns = bc_ns; a.bc_ts = bc_ts;
   a.bc_mode = scan_fwd_seq_bc_mode(B, C, io_dtype, bc_bs, bc_ns, bc_ts);
   if (a.bc_mode == 0) return SIMAMBA_E_VARIANT;
+  if (lpc == 6) {
+    a.mix_c4 = scan_fwd_seq_mix_c4(batch, dim);
+    if (a.mix_c4 == 0) return SIMAMBA_E_VARIANT;
+    const unsigned grid = static_cast<unsigned>(batch) * ((dim - a.mix_c4) / SeqCfg<2>::R + a.mix_c4 / SeqCfg<4>::R);
+    if (io_dtype == SIMAMBA_F32) {
+      if (z) hipLaunchKernelGGL((scan_fwd_seq_mix_kernel<float, true>), dim3(grid), dim3(64), 0, s, a);
+      else hipLaunchKernelGGL((scan_fwd_seq_mix_kernel<float, false>), dim3(grid), dim3(64), 0, s, a);
+    } else {
+      if (z) hipLaunchKernelGGL((scan_fwd_seq_mix_kernel<bf16_t, true>), dim3(grid), dim3(64), 0, s, a);
+      else hipLaunchKernelGGL((scan_fwd_seq_mix_kernel<bf16_t, false>), dim3(grid), dim3(64), 0, s, a);
+    }
+    return static_cast<int>(hipGetLastError());
+  }
   if (io_dtype == SIMAMBA_F32) {
     if (lpc == 2) launch_seq_lpc<float, 2>(a, s); else launch_seq_lpc<float, 4>(a, s);
   } else {

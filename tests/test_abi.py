@@ -29,13 +29,17 @@ def test_library_exports_every_declared_symbol():
 
 def test_version_strerror_and_chunks():
     lib = _lib.load()
-    assert lib.simamba_abi_version() == 6
+    assert lib.simamba_abi_version() == 7
     assert lib.simamba_strerror(0) == b"ok"
     assert b"dstate" in lib.simamba_strerror(-4)
     assert lib.simamba_scan_num_chunks(64) == 1
     assert lib.simamba_scan_num_chunks(128) == 1
     assert lib.simamba_scan_num_chunks(129) == 2
     assert lib.simamba_scan_num_chunks(1024) == 8
+    # host-side kernel choice: row-scan below 49 152 rows, two lanes per channel from there on
+    assert lib.simamba_scan_fwd_auto_variant(32, 768) == 1
+    assert lib.simamba_scan_fwd_auto_variant(64, 768) == 2
+    assert lib.simamba_scan_fwd_auto_variant(256, 768) == 2
     assert lib.simamba_spectral_workspace_bytes(4, 128) == 256 + 4 * 128 * 128 * 4
     assert b"variant" in lib.simamba_strerror(-9)
 

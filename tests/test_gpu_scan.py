@@ -279,6 +279,52 @@ def test_scan_seq_kernel_path(L, dtype, split, device):
             assert nerr(leaves[k].grad[bi:bi + 1, ds], sub[k].grad) < tol, k
 
 
+@pytest.mark.parametrize("B,D,L,dtype", [(64, 768, 160, torch.float32), (64, 768, 1024, torch.float32),
+                                         (32, 1280, 96, torch.float32), (12, 1024, 200, torch.float32),
+                                         (64, 768, 136, torch.bfloat16)])
+def test_scan_mixed_launch(B, D, L, dtype, device):
+    """SIMAMBA_SCAN_MIX: one launch in which the first channels of every sample run two lanes per channel and the last
+    ones four (an explicit variant: faster than two lanes per channel on its own at batch * dim = 49 152, slower
+    where the mixer calls it, so the library's own choice stays two lanes -- csrc/scan_fwd_seq.hip).  Whole-tensor agreement with the
+    row-scan kernel -- outputs, final state, and the gradients the backward forms from the chunk checkpoints this
+    forward wrote -- plus the oracle on a few rows on either side of the seam.  (12, 1024): batch not a multiple of
+    the 8 XCDs and every channel on four lanes; (32, 1280): seam at channel 1024."""
+    from si_mamba_amd import _lib, selective_scan_fn
+    inp = scan_inputs(B, D, L, 16, seed=B + L)
+    t = {k: v.to(device) for k, v in inp.items()}
+    for k in ("u", "delta", "z", "B", "C", "dout"):
+        t[k] = t[k].to(dtype)
+    res = {}
+    for name, variant in (("mix", _lib.SCAN_MIX), ("row", _lib.SCAN_ROWSCAN)):
+        leaves = {k: t[k].clone().requires_grad_(True) for k in ("u", "delta", "z")}
+        with _lib.scan_variant(variant):
+            out, last = selective_scan_fn(leaves["u"], leaves["delta"], t["A"], t["B"], t["C"], t["D"], leaves["z"],
+                                          t["delta_bias"], True, True)
+        out.backward(t["dout"])
+        res[name] = (out.detach(), last.detach(), {k: v.grad for k, v in leaves.items()})
+    tol = TOL[dtype]
+    assert nerr(res["mix"][0], res["row"][0]) < tol and nerr(res["mix"][1], res["row"][1]) < tol
+    for k in ("u", "delta", "z"):
+        assert nerr(res["mix"][2][k], res["row"][2][k]) < tol, k
+    if L <= 200:
+        ds = torch.tensor([0, 31, 32, D // 2, D - 257, D - 256, D - 255, D - 17, D - 16, D - 1])
+        for bi in (0, B - 1):
+            want, wlast = scan_ref.selective_scan_ref(
+                t["u"][bi:bi + 1, ds].float().cpu(), t["delta"][bi:bi + 1, ds].float().cpu(), t["A"][ds].cpu(),
+                t["B"][bi:bi + 1].float().cpu(), t["C"][bi:bi + 1].float().cpu(), t["D"][ds].cpu(),
+                t["z"][bi:bi + 1, ds].float().cpu(), t["delta_bias"][ds].cpu(), True, True)
+            assert nerr(res["mix"][0][bi:bi + 1, ds], want) < tol
+            assert nerr(res["mix"][1][bi:bi + 1, ds], wlast) < tol
+
+
+def test_scan_mixed_launch_refused_where_it_does_not_apply(device):
+    """An explicit MIX request on a shape with no half round of waves to fill is refused by name."""
+    from si_mamba_amd import _lib, selective_scan_fn
+    t = {k: v.to(device) for k, v in scan_inputs(48, 768, 64, 16, seed=5).items()}   # 1152 waves: 128 over, 85.3 channels a sample
+    with torch.no_grad(), _lib.scan_variant(_lib.SCAN_MIX), pytest.raises(RuntimeError, match="variant"):
+        selective_scan_fn(t["u"], t["delta"], t["A"], t["B"], t["C"], t["D"], t["z"], t["delta_bias"], True)
+
+
 @pytest.mark.parametrize("variant", [2, 4])
 @pytest.mark.parametrize("layout", ["token_major", "odd_strides", "ragged_dim"])
 def test_scan_seq_kernel_operand_layouts(variant, layout, device):

@@ -14,7 +14,7 @@ ap.add_argument("--shapes", default="256x768x128,64x768x1024")
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--modes", default="fwd,bwd")
 ap.add_argument("--dtype", default="f32")
-ap.add_argument("--variant", type=int, default=0, help="forward kernel: 0 auto, 1 row-scan, 2 / 4 lanes per channel")
+ap.add_argument("--variant", type=int, default=0, help="forward kernel: 0 auto, 1 row-scan, 2 / 4 lanes per channel, 6 mixed 2 + 4")
 args = ap.parse_args()
 _lib._scan_variant[0] = args.variant
 dev = torch.device("cuda:0")
