@@ -50,7 +50,8 @@ def traffic_from_profiles(kernel, shape):
 
 
 def cpu_baseline(npts, groups, seed=0):
-    """Oracle port of the same training step (same architecture, fp32) on a bounded 2-cloud sample."""
+    """Oracle port of the same training step (same architecture, fp32) on a bounded sample: one warm-up step of 2
+    clouds (thread pools, allocator), then two timed steps of 4 clouds each (about 20 s of CPU work)."""
     from oracle import fps_ref, scan_ref, spectral_ref
     from si_mamba_amd.point_mamba import PointMamba, default_config
     from si_mamba_amd.synthetic import make_clouds
@@ -73,17 +74,24 @@ def cpu_baseline(npts, groups, seed=0):
     m.spectral_order = spectral_order
     m.group_divider.fps_fn = fps_ref.sample_farthest_points
     m.train()
-    B = 2
-    pts = make_clouds(B, npts, seed, "cpu")
-    gt = torch.randint(0, cfg.cls_dim, (B,))
-    t0 = time.perf_counter()
-    loss, _ = m.get_loss_acc(m(pts), gt)
-    loss.backward()
-    dt = time.perf_counter() - t0
-    return {"value": round(B / dt, 4), "unit": "point-clouds/s", "cores": torch.get_num_threads(),
+    def one_step(B, seed):
+        pts = make_clouds(B, npts, seed, "cpu")
+        gt = torch.randint(0, cfg.cls_dim, (B,))
+        t0 = time.perf_counter()
+        loss, _ = m.get_loss_acc(m(pts), gt)
+        loss.backward()
+        m.zero_grad(set_to_none=True)
+        return time.perf_counter() - t0
+
+    one_step(2, seed)
+    B, steps = 4, 2
+    dts = [one_step(B, seed + 1 + i) for i in range(steps)]
+    dt = sum(dts)
+    return {"value": round(B * steps / dt, 4), "unit": "point-clouds/s", "cores": torch.get_num_threads(),
             "kind": "port",
-            "sample": f"{B} clouds, same 12-block d=384 model, fwd+bwd once, oracle mixers + torch.linalg.eigh "
-                      f"ordering ({dt:.1f} s)"}
+            "sample": f"{steps} steps of {B} clouds after a 2-cloud warm-up step, same 12-block d=384 model, fwd+bwd, "
+                      f"oracle mixers + torch.linalg.eigh ordering ({dt:.1f} s; per step "
+                      f"{', '.join(f'{x:.1f}' for x in dts)} s)"}
 
 
 def headline_scan(device, iters=30):
@@ -156,6 +164,40 @@ def headline_scan(device, iters=30):
         nbytes = scan_fwd_bytes(B, D, L, N) if mode == "fwd" else scan_bwd_bytes(B, D, L, N)
         res[mode].update({"kernel_ms": round(ms, 4), "kernel_GB/s": round(nbytes / ms / 1e6, 1),
                           "kernel_frac_of_8TBs": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4)})
+    # the same trains with bf16 operands and results (fp32 A / D / bias / accumulators, fp32 arithmetic inside): the I/O
+    # type of the autocast configurations; half the bytes through the same instruction stream
+    h = {k: d[k].to(torch.bfloat16) for k in ("u", "delta", "z", "B", "C", "dout")}
+    outh = torch.empty_like(h["u"])
+    duh, ddh, dzh = (torch.empty_like(h["u"]) for _ in range(3))
+
+    def fwd16():
+        return lib.simamba_selective_scan_fwd(h["u"].data_ptr(), h["delta"].data_ptr(), d["A"].data_ptr(),
+                                              h["B"].data_ptr(), h["C"].data_ptr(), d["D"].data_ptr(), h["z"].data_ptr(),
+                                              d["delta_bias"].data_ptr(), outh.data_ptr(), None, None, B, D, L, N,
+                                              _lib.BF16, 1, 0, 0, 0, 0, 0, st)
+
+    def bwd16():
+        return lib.simamba_selective_scan_bwd(h["u"].data_ptr(), h["delta"].data_ptr(), d["A"].data_ptr(),
+                                              h["B"].data_ptr(), h["C"].data_ptr(), d["D"].data_ptr(), h["z"].data_ptr(),
+                                              d["delta_bias"].data_ptr(), h["dout"].data_ptr(), None, duh.data_ptr(),
+                                              ddh.data_ptr(), acc[0].data_ptr(), acc[1].data_ptr(), acc[2].data_ptr(),
+                                              acc[3].data_ptr(), dzh.data_ptr(), acc[4].data_ptr(), B, D, L, N,
+                                              _lib.BF16, 1, 0, 0, 0, 0, 0, st)
+
+    res["bf16_io"] = {}
+    for mode, fn in (("fwd", fwd16), ("bwd", bwd16)):
+        for _ in range(5):
+            assert fn() == 0
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(iters):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        ms = a.elapsed_time(b) / iters
+        nbytes = scan_fwd_bytes(B, D, L, N, 2) if mode == "fwd" else scan_bwd_bytes(B, D, L, N, 2)
+        res["bf16_io"][mode] = {"kernel_ms": round(ms, 4), "kernel_GB/s": round(nbytes / ms / 1e6, 1),
+                                "kernel_frac_of_8TBs": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4)}
     res["shape"] = [B, D, L, N]
     res["note"] = ("ms: one event-bracketed call of the Python op (includes the launch gap of an idle stream); kernel_ms: "
                    "a train of back-to-back C-ABI launches / their number (kernel + boundary; bwd includes its memset "

@@ -92,8 +92,18 @@ SPECTRAL_COMBOS = [
 ]
 
 
-def spectral_case(name, B, G, seed, k=4):
-    centers = unit_ball_centers(B, G, seed)
+def surface_centers(B, G, seed, npoints=1024):
+    """Patch centres as the pipeline makes them: farthest-point sampling (oracle/fps_ref.py) of clouds on thin surfaces."""
+    from oracle import fps_ref
+    from si_mamba_amd.synthetic import surface_clouds
+    pts = surface_clouds(B, npoints, seed)
+    idx = fps_ref.sample_farthest_points(pts, G)
+    idx = idx[1] if isinstance(idx, tuple) else idx
+    return torch.gather(pts, 1, idx.long()[..., None].expand(-1, -1, 3)).contiguous()
+
+
+def spectral_case(name, B, G, seed, k=4, centers=None):
+    centers = unit_ball_centers(B, G, seed) if centers is None else centers
     rec = {"centers": centers.numpy()}
     for cb in SPECTRAL_COMBOS:
         adj = spectral_ref.create_graph_from_feature_space(centers, cb["knn"], cb["alpha"], cb["symmetric"],
@@ -179,6 +189,7 @@ def main():
     mamba_block_case()
     spectral_case("spectral_g64", 4, 64, 0)
     spectral_case("spectral_g128", 2, 128, 1)
+    spectral_case("spectral_g128_surface", 4, 128, 7, centers=surface_centers(4, 128, 7))
     interp_case("interp_seg", 2, 256, 32, 48, 4)
     chamfer_case("chamfer_mae", 64, 32, 32, 5)
     param_table()

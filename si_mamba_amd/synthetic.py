@@ -35,6 +35,20 @@ def unit_ball_centers(B, G, seed):
     return p / p.norm(dim=-1).max(dim=1)[0][:, None, None]
 
 
+def surface_clouds(B, N, seed):
+    """(B, N, 3) clouds sampled on thin closed surfaces (a torus of random aspect per cloud, 2 % radial noise),
+    pc_norm'ed: object scans are 2-D sheets, not Gaussian blobs -- their k-NN graphs are far more regular and their
+    Laplacians have closer eigenvalue pairs."""
+    g = torch.Generator().manual_seed(seed)
+    a, b = 2 * torch.pi * torch.rand(B, N, generator=g), 2 * torch.pi * torch.rand(B, N, generator=g)
+    r = 0.25 + 0.3 * torch.rand(B, 1, generator=g)
+    rad = 1.0 + r * torch.cos(b)
+    p = torch.stack([rad * torch.cos(a), rad * torch.sin(a), (0.6 + 0.8 * torch.rand(B, 1, generator=g)) * r * torch.sin(b)], -1)
+    p = p * (1.0 + 0.02 * torch.randn(B, N, 1, generator=g))
+    p = p - p.mean(1, keepdim=True)
+    return p / p.norm(dim=-1).max(dim=1)[0][:, None, None]
+
+
 def make_clouds(B, N, seed, device="cpu"):
     """(B, N, 3) clouds: N(0, I_3) points, pc_norm (datasets/ShapeNet55Dataset.py:47-53)."""
     return unit_ball_centers(B, N, seed).to(device)

@@ -5,7 +5,7 @@ import torch
 
 from conftest import load_golden
 from oracle import spectral_ref as sr
-from oracle.gen_golden import SPECTRAL_COMBOS, unit_ball_centers
+from oracle.gen_golden import SPECTRAL_COMBOS, surface_centers, unit_ball_centers
 
 
 def test_eigh_reads_lower_triangle_only():
@@ -30,10 +30,12 @@ def test_graph_properties():
     assert torch.all(torch.diagonal(adj_s, dim1=1, dim2=2) == 1.0)
 
 
-@pytest.mark.parametrize("name,B,G,seed", [("spectral_g64", 4, 64, 0), ("spectral_g128", 2, 128, 1)])
+@pytest.mark.parametrize("name,B,G,seed", [("spectral_g64", 4, 64, 0), ("spectral_g128", 2, 128, 1),
+                                           ("spectral_g128_surface", 4, 128, 7)])
 def test_spectral_golden_regression(name, B, G, seed):
     g = load_golden(name)
-    centers = unit_ball_centers(B, G, seed)
+    # "_surface": FPS centres of clouds on thin closed surfaces (close eigenvalue pairs), the others Gaussian blobs
+    centers = surface_centers(B, G, seed) if name.endswith("_surface") else unit_ball_centers(B, G, seed)
     np.testing.assert_array_equal(centers.numpy(), g["centers"])
     for cb in SPECTRAL_COMBOS:
         t = cb["tag"]

@@ -2,7 +2,10 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from si_mamba_amd import _lib, selective_scan_fn
+from si_mamba_amd import _lib
+if os.environ.get("SIMAMBA_LIB"):
+    _lib.LIB_PATH = os.environ["SIMAMBA_LIB"]
+from si_mamba_amd import selective_scan_fn
 from si_mamba_amd.synthetic import scan_inputs
 
 dev = torch.device("cuda:0")
@@ -18,11 +21,21 @@ def scan(grad):
     with torch.no_grad():
         return selective_scan_fn(t["u"], t["delta"], t["A"], t["B"], t["C"], t["D"], t["z"], t["delta_bias"], True)
 
+hid = torch.randn(B * L, 384, device=dev); wz = torch.randn(384, D, device=dev) / 20
+zbuf = torch.empty(B * L, D, device=dev)
+
+def gemm_z():        # the z half of in_proj as a GEMM of its own between the producer of u / delta and the scan
+    torch.mm(hid, wz, out=zbuf)
+
 contexts = {
     "back to back": lambda: None,
     "after a GEMM": lambda: torch.mm(a_mat, b_mat),
     "after a 400 MB fill": lambda: big.fill_(1.0),
     "after GEMM + fill": lambda: (torch.mm(a_mat, b_mat), big.fill_(1.0)),
+    "fill, then z GEMM": lambda: (big.fill_(1.0), gemm_z()),
+    "after a 400 MB read": lambda: big.sum(),
+    "after a 200 MB fill": lambda: big[:50 * 1024 * 1024].fill_(1.0),
+    "after a 100 MB fill": lambda: big[:25 * 1024 * 1024].fill_(1.0),
 }
 for grad in (False, True):
     for cname, pre in contexts.items():
