@@ -5,7 +5,13 @@
                   additive term that replaces the reference's concat of the global feature (:64-66)
   group_max_fn    max over the points of a patch   reference :63, :68  (torch.max(..., dim=2)[0])
 
-Both are plain autograd Functions over the C ABI; BatchNorm keeps nn.BatchNorm1d's buffers (running_mean,
+  token_linear    y = x W^T + b on a token-major (rows, C) view (the reference's 1x1 Conv1d, :44-57) whose weight
+                  gradient is a split-K batched product: dW = sum_s dY_s^T X_s over 64 row slabs, fp32 partials.
+                  The one-GEMM form autograd would run has K = rows = 262 144 and a (C_out, C_in) result of a few
+                  tiles: the library's kernels for it leave most of the chip idle (bf16: 540-790 us per layer
+                  against 44-143 us split; fp32: 443-1 778 against 156-750 us; tools/bench_wgrad_splitk.py).
+
+bn_relu_fn and group_max_fn are plain autograd Functions over the C ABI; BatchNorm keeps nn.BatchNorm1d's buffers (running_mean,
 running_var, num_batches_tracked) and train/eval semantics.
 """
 from __future__ import annotations
@@ -17,6 +23,52 @@ from . import _lib
 
 _BN_MAX_C = 1024     # channels per kernel call; wider layers go slice by slice (in place, row stride = C)
 _BN_CHUNK = 256      # rows per workgroup in csrc/bn_relu.hip: the granularity of its per-group dx sums
+
+
+_SPLITK = 64         # row slabs of token_linear's weight gradient
+_SPLITK_MIN_ROWS = 512   # per slab; below it the plain product is used
+
+
+class TokenLinearFn(torch.autograd.Function):
+    """F.linear on (rows, C_in) tokens with a split-K weight gradient (library GEMMs; no custom kernel)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        y = torch.nn.functional.linear(x, weight, bias)       # under autocast: the reference's rounding (bf16 GEMM)
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        io = dy.dtype
+        rows, n_out = dy.shape
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = (dy @ weight.to(io)).to(x.dtype)
+        if ctx.needs_input_grad[1]:
+            xc = x.to(io).contiguous()
+            if rows % _SPLITK == 0 and rows // _SPLITK >= _SPLITK_MIN_ROWS:
+                m = rows // _SPLITK
+                a = dy.view(_SPLITK, m, n_out).transpose(1, 2)
+                b = xc.view(_SPLITK, m, xc.shape[1])
+                part = torch.bmm(a, b) if io == torch.float32 else torch.bmm(a, b, out_dtype=torch.float32)
+                dw = part.sum(0).to(weight.dtype)
+            else:
+                dw = (dy.t() @ xc).to(weight.dtype)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dy.sum(0, dtype=torch.float32).to(weight.dtype)
+        return dx, dw, db
+
+
+def token_linear(x, weight, bias=None):
+    """(rows, C_in) @ (C_out, C_in)^T + bias.  GPU tensors take the split-K weight gradient; anything else is
+    torch.nn.functional.linear."""
+    if x.is_cuda and x.dim() == 2 and torch.is_grad_enabled() and (weight.requires_grad or x.requires_grad):
+        return TokenLinearFn.apply(x, weight, bias)
+    return torch.nn.functional.linear(x, weight, bias)
 
 
 def _slices(C):

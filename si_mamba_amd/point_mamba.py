@@ -21,7 +21,7 @@ import torch.nn as nn
 
 from . import grouping, spectral
 from .block import MixerModel
-from .encoder_ops import bn_relu_fn, group_max_fn
+from .encoder_ops import bn_relu_fn, group_max_fn, token_linear
 
 
 class Group(nn.Module):
@@ -81,6 +81,7 @@ class Encoder(nn.Module):
         lin = torch.nn.functional.linear
         x = point_groups.reshape(bs * g * n, 3)
         if self.fused and x.is_cuda and 256 % n == 0:
+            lin = token_linear                            # same product; split-K weight gradient (encoder_ops.py)
             x = bn_relu_fn(lin(x, c1.weight.squeeze(-1), c1.bias), bn1)
             f = lin(x, c2.weight.squeeze(-1), c2.bias)                                  # (B*G*n, 256)
             cf = f.shape[1]

@@ -28,7 +28,7 @@ import torch.nn.functional as F
 from . import spectral
 from .add_norm import add_layer_norm_fn
 from .block import DropPath, _init_weights, create_block
-from .encoder_ops import bn_relu_fn
+from .encoder_ops import bn_relu_fn, token_linear
 from .interp import three_interpolate, three_nn
 from .point_mamba import Encoder, Group
 
@@ -109,10 +109,10 @@ class PointNetFeaturePropagation(nn.Module):
             h = F.linear(points1.reshape(B * N, d1).to(interp.dtype), w0[:, :d1], self.mlp_convs[0].bias)
             h = torch.addmm(h, interp, w0[:, d1:].t().to(interp.dtype))
         else:
-            h = F.linear(interp, w0, self.mlp_convs[0].bias)
+            h = token_linear(interp, w0, self.mlp_convs[0].bias)
         h = bn_relu_fn(h, self.mlp_bns[0])
         for conv, bn in zip(list(self.mlp_convs)[1:], list(self.mlp_bns)[1:]):
-            h = bn_relu_fn(F.linear(h, conv.weight.squeeze(-1), conv.bias), bn)
+            h = bn_relu_fn(token_linear(h, conv.weight.squeeze(-1), conv.bias), bn)
         return h
 
 
@@ -215,14 +215,14 @@ class PartSegMamba(nn.Module):
         w1 = self.convs1.weight.squeeze(-1)
         nf0 = f0.shape[1]
         gterm = F.linear(glob, w1[:, nf0:], self.convs1.bias)                   # (B, 512)
-        h = F.linear(f0, w1[:, :nf0])
+        h = token_linear(f0, w1[:, :nf0])
         if N % 256 == 0 or 256 % N == 0:
             h = bn_relu_fn(h, self.bns1, gterm=gterm, group=N)
         else:
             h = bn_relu_fn(h + gterm.repeat_interleave(N, dim=0).to(h.dtype), self.bns1)
         h = self.dp1(h)
-        h = bn_relu_fn(F.linear(h, self.convs2.weight.squeeze(-1), self.convs2.bias), self.bns2)
-        h = F.linear(h, self.convs3.weight.squeeze(-1), self.convs3.bias)
+        h = bn_relu_fn(token_linear(h, self.convs2.weight.squeeze(-1), self.convs2.bias), self.bns2)
+        h = token_linear(h, self.convs3.weight.squeeze(-1), self.convs3.bias)
         return F.log_softmax(h.float(), dim=-1).view(B, N, self.cls_dim)
 
 
