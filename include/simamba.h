@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define SIMAMBA_ABI_VERSION 7
+#define SIMAMBA_ABI_VERSION 8
 
 #define SIMAMBA_F32  0
 #define SIMAMBA_BF16 1
@@ -133,19 +133,21 @@ int simamba_selective_scan_bwd(const void* u, const void* delta, const float* A,
  *   xdbl[b, t, s]  = sum_d wx[s, d] * x[b, d, t]            (batch, seqlen, S) token-major, S = dt_rank + 2 * dstate
  *   delta[b, d, t] = sum_r wdt[d, r] * xdbl[b, t, r], r < R (batch, D, seqlen)
  *   x : (batch, D, seqlen), seqlen contiguous, batch stride x_bstride elements (0 => D * seqlen);
- *   wx : (S, D) fp32 ; wdt : (D, R) fp32.  SIMAMBA_F32 only (exact fp32 MFMA, v_mfma_f32_32x32x2_f32);
- *   D % 64 == 0, D * seqlen * 4 < 2^32 (one sample is one buffer descriptor), seqlen % 4 == 0, S % 4 == 0, S <= 64,
+ *   wx : (S, D), wdt : (D, R), both in the I/O type.  SIMAMBA_F32: exact fp32 MFMA (v_mfma_f32_32x32x2_f32);
+ *   SIMAMBA_BF16: v_mfma_f32_32x32x16_bf16 with fp32 accumulation and the roundings of the reference's autocast
+ *   run (x_conv, x_dbl, delta each rounded once; delta formed from the rounded dt rows).
+ *   D % 64 == 0, D * seqlen * 4 < 2^32 (one sample is one buffer descriptor), seqlen % 4 == 0 (bf16: % 8), S % 4 == 0, S <= 64,
  *   R % 4 == 0, 4 <= R <= 24, 16-byte aligned pointers; anything else returns SIMAMBA_E_SHAPE / _ALIGN (the host
  *   mirror then takes the two library GEMMs).
  */
-int simamba_xdt_proj_fwd(const void* x, const float* wx, const float* wdt, void* xdbl, void* delta,
+int simamba_xdt_proj_fwd(const void* x, const void* wx, const void* wdt, void* xdbl, void* delta,
                          int batch, int D, int seqlen, int S, int R, int io_dtype, long long x_bstride,
                          void* stream);
 /* The same with the causal depthwise conv1d (width 4, bias cb or NULL, + SiLU) of the mixer applied to x on the way
  * in (causal_conv1d_fn inside the same mamba_inner_fn): xconv (batch, D, seqlen) receives silu(conv(x)) -- what the
  * scan and the backward read -- so conv, x_proj and dt_proj are one pass over the in_proj output's x half.
  * D <= 1024 (taps and bias are held in LDS). */
-int simamba_conv_xdt_proj_fwd(const void* x, const float* cw, const float* cb, const float* wx, const float* wdt,
+int simamba_conv_xdt_proj_fwd(const void* x, const float* cw, const float* cb, const void* wx, const void* wdt,
                               void* xconv, void* xdbl, void* delta, int batch, int D, int seqlen, int S, int R,
                               int io_dtype, long long x_bstride, void* stream);
 

@@ -28,7 +28,7 @@ SCAN_AUTO, SCAN_ROWSCAN, SCAN_LPC2, SCAN_LPC4, SCAN_MIX = 0, 1, 2, 4, 6
 # name -> (restype, argtypes); mirrors include/simamba.h one to one
 _P = c_void_p
 _LL = c_longlong
-ABI_VERSION = 7
+ABI_VERSION = 8
 SIGNATURES = {
     "simamba_abi_version": (c_int, []),
     "simamba_strerror": (c_char_p, [c_int]),

@@ -114,16 +114,16 @@ __global__ __launch_bounds__(kXdtThreads, 2) void xdt_proj_f32_kernel(XdtArgs p)
   const int li = lane & 31, hh = lane >> 5;
   const int sblk = wave & 1, tblk = wave >> 1;
   const int D = p.D, L = p.L, S = p.S, R = p.R;
-  const int tps = (L + kTok - 1) / kTok;                  // tiles per sample
+  const int tps = __builtin_amdgcn_readfirstlane((L + kTok - 1) / kTok);   // tiles per sample
   const int ntiles = p.batch * tps;
   const int nwg = static_cast<int>(gridDim.x), wg = static_cast<int>(blockIdx.x);
   // this workgroup's tiles: wg, wg + nwg, ... (the host evens the counts out and keeps all workgroups resident)
-  const int ntw = (ntiles - wg + nwg - 1) / nwg;
+  const int ntw = __builtin_amdgcn_readfirstlane((ntiles - wg + nwg - 1) / nwg);
   if (ntw <= 0) return;
   const int nk = D / kKS;                                 // steps per tile; even (host: D % 64 == 0)
   const int ndb = D / 32;                                 // 32-channel blocks of delta; wave w owns w, w + 4, ...
   const int nunits = wave < ndb ? 2 * ((ndb - wave + 3) / 4) : 0;   // (d-block, token block) units of this wave per tile
-  const int gq = nwg / tps, gr = nwg - gq * tps;          // the tile stride nwg as (samples, tiles of a sample)
+  const int gq = __builtin_amdgcn_readfirstlane(nwg / tps), gr = nwg - gq * tps;          // the tile stride nwg as (samples, tiles of a sample)
   const unsigned sample_bytes = static_cast<unsigned>(D) * static_cast<unsigned>(L) * 4u;   // host: < 2^32
 
   for (int i = tid; i < 24 * kTok; i += kXdtThreads) sDt[i] = 0.f;   // rows >= R stay zero
@@ -166,7 +166,17 @@ __global__ __launch_bounds__(kXdtThreads, 2) void xdt_proj_f32_kernel(XdtArgs p)
   struct Ops { float a[16], b[16]; };
 
   // global loads of a step (zeros past the tile's end, past row S, and for a step past the last tile)
-  auto issue = [&](Stage& st, const Cursor& c) {
+  // Cursor fields enter descriptors and scalar offsets.  In the loop they live in SGPRs anyway; in the prologue hipcc
+  // had them in VGPRs, could not prove them uniform and wrapped those buffer loads in waterfall loops -- whose loads
+  // its s_waitcnt bookkeeping counts once although the counter sees every trip: the first conv read its neighbours'
+  // packs (DPP) before they had landed, on some workgroups, on some runs (tests/test_gpu_xdt_proj.py caught it on
+  // the bf16 form; the fp32 form had the same loops).  readfirstlane makes the uniformity explicit: no waterfall.
+  auto uniform = [](const Cursor& c) {                    // the same values, provably wave-uniform (SGPRs)
+    return Cursor{__builtin_amdgcn_readfirstlane(c.j), __builtin_amdgcn_readfirstlane(c.ks),
+                  __builtin_amdgcn_readfirstlane(c.q), __builtin_amdgcn_readfirstlane(c.r)};
+  };
+  auto issue = [&](Stage& st, const Cursor& c_) {
+    const Cursor c = uniform(c_);
     const rsrc_t rs = make_rsrc(p.x + static_cast<size_t>(c.q) * p.x_bs, c.j < ntw ? sample_bytes : 0u);
     const int t0 = c.r * kTok;
     const unsigned soff = (static_cast<unsigned>(c.ks) * kKS * L + t0) * 4u;
@@ -181,7 +191,8 @@ __global__ __launch_bounds__(kXdtThreads, 2) void xdt_proj_f32_kernel(XdtArgs p)
     }
   };
   // conv + SiLU (kConv), x_conv out, LDS tiles of the step
-  auto stage = [&](const Stage& st, const Cursor& c, int buf) {
+  auto stage = [&](const Stage& st, const Cursor& c_, int buf) {
+    const Cursor c = uniform(c_);
     rsrc_t rs_xc;
     unsigned soff = 0;
     bool xok = true;
@@ -250,7 +261,8 @@ __global__ __launch_bounds__(kXdtThreads, 2) void xdt_proj_f32_kernel(XdtArgs p)
 #pragma unroll
   for (int g = 0; g < 3; ++g) wdoff[g] = (8 * g + 4 * hh < R) ? (static_cast<unsigned>(li) * R + 4 * hh + 8 * g) * 4u : kOob;
   const unsigned dvoff = (static_cast<unsigned>(4 * hh) * L + li) * 4u;   // delta: row 4 hh, column li of a 32 x 32 block
-  auto wload = [&](int u) {                                // the Wdt rows of unit u (and u + 1: same d-block)
+  auto wload = [&](int u_) {
+    const int u = __builtin_amdgcn_readfirstlane(u_);                                // the Wdt rows of unit u (and u + 1: same d-block)
     const int db = wave + 4 * (u >> 1);
     const unsigned soff = db < ndb ? static_cast<unsigned>(db) * 32u * R * 4u : 0u;
 #pragma unroll
@@ -270,7 +282,9 @@ __global__ __launch_bounds__(kXdtThreads, 2) void xdt_proj_f32_kernel(XdtArgs p)
 #pragma unroll
     for (int m = 0; m < kM2; ++m) o = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[m], b2[m], o, 0, 0, 0);
   };
-  auto unit_store = [&](int u, const f32x16& o, int q, int r) {   // tile (sample q, tile r of it)
+  auto unit_store = [&](int u_, const f32x16& o, int q_, int r_) {
+    const int u = __builtin_amdgcn_readfirstlane(u_), q = __builtin_amdgcn_readfirstlane(q_),
+              r = __builtin_amdgcn_readfirstlane(r_);   // tile (sample q, tile r of it)
     const int db = wave + 4 * (u >> 1);
     const rsrc_t rs = make_rsrc(p.delta + static_cast<size_t>(q) * D * L, db < ndb ? sample_bytes : 0u);
     const int tb0 = r * kTok + (u & 1) * 32;
@@ -286,7 +300,9 @@ __global__ __launch_bounds__(kXdtThreads, 2) void xdt_proj_f32_kernel(XdtArgs p)
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
   Stage s0, s1;
   Ops o0;
-  const int q0 = wg / tps;
+  // uniform values kept in SGPRs (integer division runs on the VALU): descriptors built from them are provably
+  // wave-uniform, no waterfall loop wraps the prologue's buffer loads and hipcc's vmcnt counts stay exact
+  const int q0 = __builtin_amdgcn_readfirstlane(wg / tps);
   Cursor cm{0, 0, q0, wg - q0 * tps};                     // step g            (MFMAs)
   Cursor cr = cm, cs = cm, cl = cm;
   advance(cr, 1);                                          // step g + 1        (operand reads)
@@ -387,15 +403,23 @@ __global__ __launch_bounds__(kXdtThreads, 2) void xdt_proj_f32_kernel(XdtArgs p)
 
 using namespace simamba;
 
-static int xdt_launch(const void* x, const float* cw, const float* cb, const float* wx, const float* wdt, void* xconv,
+// xdt_proj_bf16.hip
+int xdt_launch_bf16(const void* x, const float* cw, const float* cb, const void* wx, const void* wdt, void* xconv,
+                    void* xdbl, void* delta, int batch, int D, int L, int S, int R, long long x_bs, bool conv,
+                    hipStream_t stream);
+
+static int xdt_launch(const void* x, const float* cw, const float* cb, const void* wx_, const void* wdt_, void* xconv,
                       void* xdbl, void* delta, int batch, int D, int L, int S, int R, int io_dtype,
                       long long x_bstride, bool conv, void* stream) {
   if (batch < 0 || D <= 0 || L < 0 || batch > 65535) return SIMAMBA_E_SHAPE;
-  if (io_dtype != SIMAMBA_F32) return SIMAMBA_E_DTYPE;
-  if (D % 64 || L % 4 || S % 4 || S > kSPad || S < R || R % 4 || R > 24 || R < 4) return SIMAMBA_E_SHAPE;
+  if (io_dtype != SIMAMBA_F32 && io_dtype != SIMAMBA_BF16) return SIMAMBA_E_DTYPE;
+  const int pack = io_dtype == SIMAMBA_F32 ? 4 : 8;      // elements per 16-byte access
+  if (D % 64 || L % pack || S % 4 || S > kSPad || S < R || R % 4 || R > 24 || R < 4) return SIMAMBA_E_SHAPE;
   if (conv && D > kMaxDConv) return SIMAMBA_E_SHAPE;
   if (static_cast<long long>(D) * L * 4 >= (1LL << 32) - 65536 || static_cast<long long>(S) * D * 4 >= (1LL << 31)) return SIMAMBA_E_SHAPE;
   if (batch == 0 || L == 0) return SIMAMBA_OK;
+  const float* wx = static_cast<const float*>(wx_);
+  const float* wdt = static_cast<const float*>(wdt_);
   if (!x || !wx || !wdt || !xdbl || !delta || (conv && (!cw || !xconv))) return SIMAMBA_E_NULLPTR;
   uintptr_t al = reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(wx) | reinterpret_cast<uintptr_t>(wdt) |
                  reinterpret_cast<uintptr_t>(xdbl) | reinterpret_cast<uintptr_t>(delta);
@@ -407,7 +431,11 @@ static int xdt_launch(const void* x, const float* cw, const float* cb, const flo
   a.xdbl = static_cast<float*>(xdbl); a.delta = static_cast<float*>(delta);
   a.batch = batch; a.D = D; a.L = L; a.S = S; a.R = R;
   a.x_bs = x_bstride ? x_bstride : static_cast<long long>(D) * L;
-  if (a.x_bs % 4) return SIMAMBA_E_ALIGN;
+  if (a.x_bs % pack) return SIMAMBA_E_ALIGN;
+  if (static_cast<long long>(batch) * ((L + kTok - 1) / kTok) > 0x7fffffffLL) return SIMAMBA_E_SHAPE;
+  if (io_dtype == SIMAMBA_BF16)
+    return xdt_launch_bf16(x, cw, cb, wx_, wdt_, xconv, xdbl, delta, batch, D, L, S, R, a.x_bs, conv,
+                           static_cast<hipStream_t>(stream));
   // grid: every workgroup the same number of tiles, all workgroups resident together (2 per CU, 256 CUs)
   const long long ntiles = static_cast<long long>(batch) * ((L + kTok - 1) / kTok);
   if (ntiles > 0x7fffffffLL) return SIMAMBA_E_SHAPE;
@@ -425,8 +453,8 @@ static int xdt_launch(const void* x, const float* cw, const float* cb, const flo
   return static_cast<int>(hipGetLastError());
 }
 
-// fp32 only (bf16 mixers keep the library GEMMs); D % 64 == 0, L % 4 == 0, S % 4 == 0, S <= 64, R % 4 == 0, R <= 24.
-extern "C" int simamba_xdt_proj_fwd(const void* x, const float* wx, const float* wdt, void* xdbl, void* delta,
+// D % 64 == 0, L % 4 == 0 (bf16: 8), S % 4 == 0, S <= 64, R % 4 == 0, R <= 24; wx / wdt in the I/O type.
+extern "C" int simamba_xdt_proj_fwd(const void* x, const void* wx, const void* wdt, void* xdbl, void* delta,
                                     int batch, int D, int L, int S, int R, int io_dtype, long long x_bstride,
                                     void* stream) {
   return xdt_launch(x, nullptr, nullptr, wx, wdt, nullptr, xdbl, delta, batch, D, L, S, R, io_dtype, x_bstride, false,
@@ -434,8 +462,8 @@ extern "C" int simamba_xdt_proj_fwd(const void* x, const float* wx, const float*
 }
 
 // The same with the mixer's causal depthwise conv1d (width 4, + SiLU) applied to x on the way in; xconv receives it.
-extern "C" int simamba_conv_xdt_proj_fwd(const void* x, const float* cw, const float* cb, const float* wx,
-                                         const float* wdt, void* xconv, void* xdbl, void* delta, int batch, int D, int L,
+extern "C" int simamba_conv_xdt_proj_fwd(const void* x, const float* cw, const float* cb, const void* wx,
+                                         const void* wdt, void* xconv, void* xdbl, void* delta, int batch, int D, int L,
                                          int S, int R, int io_dtype, long long x_bstride, void* stream) {
   return xdt_launch(x, cw, cb, wx, wdt, xconv, xdbl, delta, batch, D, L, S, R, io_dtype, x_bstride, true, stream);
 }

@@ -1,0 +1,362 @@
+// bf16 form of the fused conv1d + SiLU -> x_proj -> dt_proj kernel (xdt_proj.hip holds the fp32 form and the story of
+// the schedule): bf16 operands and results, v_mfma_f32_32x32x16_bf16, fp32 accumulation.
+//
+// What the reference's mixer does under torch.autocast (tools/runner_pretrain.py:243; upstream mamba_inner_fn reached
+// from models/block.py:72): the conv output, x_dbl and delta are bf16 tensors, each product accumulates in fp32 and
+// rounds once.  The same roundings happen here: silu(conv(x)) is rounded to bf16 and that value is both stored as
+// x_conv and fed to the matrix cores; x_dbl is rounded when it leaves the accumulator and the ROUNDED dt rows are the
+// B operand of the delta product; delta is rounded when stored.
+//
+// Differences from the fp32 form, all forced by the operand shape of the 16-bit MFMA (a lane carries 8 consecutive k):
+//   * x tile in LDS stays [d][t] (t contiguous, as loaded); the B operand -- 8 consecutive d for one t -- is gathered with
+//     8 ds_read_u16 per MFMA (two lanes share every bank word: conflict-free; a transposing store would put 16 lanes
+//     on one bank);
+//   * Wx tile [s][d] bf16, 80-byte pitch: the A operand is one ds_read_b128 per MFMA;
+//   * the dt rows of a finished tile wait in LDS as [t][r] bf16 (an accumulator lane owns 4 consecutive r of one t:
+//     one 8-byte store), rows r >= R zeroed (they pad K = R = 24 to the 32 of two MFMAs), read back as ds_read_b128;
+//   * delta leaves as 2-byte stores, 32 lanes on 64 contiguous bytes of a row (the other half of the line follows from
+//     the unit of the neighbouring token block, two iterations later).
+// A step moves half the bytes of the fp32 form and needs an eighth of its MFMAs; registers allow 3 workgroups per CU.
+#include "common.h"
+#include <type_traits>
+
+namespace simamba {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int kHThreads = 256;
+constexpr int kHTok = 64;           // tokens per tile
+constexpr int kHKS = 32;            // d per step
+constexpr int kHXP = kHTok;         // x tile pitch (bf16 elements): 128-byte rows
+constexpr int kHWP = kHKS + 8;      // Wx tile pitch: 80 bytes
+constexpr int kHDP = 32 + 8;        // dt image pitch: 80 bytes
+constexpr int kHMaxDConv = 1024;
+constexpr unsigned kHOob = 0xfffff000u;
+
+struct XdtHArgs {
+  const uint16_t* x;      // (batch, D, L) bf16; with kConv the conv INPUT
+  const float* cw;        // (D, 4) fp32 taps
+  const float* cb;        // (D) fp32 or NULL
+  uint16_t* xconv;        // kConv: (batch, D, L) bf16
+  const uint16_t* wx;     // (S, D) bf16
+  const uint16_t* wdt;    // (D, R) bf16
+  uint16_t* xdbl;         // (batch, L, S) bf16
+  uint16_t* delta;        // (batch, D, L) bf16
+  int batch, D, L, S, R;
+  long long x_bs;
+};
+
+using hrsrc_t = __amdgpu_buffer_rsrc_t;
+__device__ __forceinline__ hrsrc_t hmake_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, static_cast<int>(bytes), 0x00020000);
+}
+using hvec4_t = decltype(__builtin_amdgcn_raw_buffer_load_b128(hmake_rsrc(nullptr, 0u), 0u, 0u, 0));
+using hvec2_t = decltype(__builtin_amdgcn_raw_buffer_load_b64(hmake_rsrc(nullptr, 0u), 0u, 0u, 0));
+__device__ __forceinline__ uint4 hload16(hrsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ void hstore16(uint4 v, hrsrc_t r, unsigned voff, unsigned soff) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(hvec4_t, v), r, voff, soff, 0);
+}
+__device__ __forceinline__ void hstore2(unsigned short v, hrsrc_t r, unsigned voff, unsigned soff) {
+  __builtin_amdgcn_raw_buffer_store_b16(v, r, voff, soff, 0);
+}
+__device__ __forceinline__ float hlo(unsigned w) { return __builtin_bit_cast(float, w << 16); }
+__device__ __forceinline__ float hhi(unsigned w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
+__device__ __forceinline__ unsigned hpack(float a, float b) {
+  return static_cast<unsigned>(f32_to_bf16(a)) | (static_cast<unsigned>(f32_to_bf16(b)) << 16);
+}
+__device__ __forceinline__ unsigned hdpp_prev(unsigned v) {
+  return static_cast<unsigned>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), DPP_ROW_SHR + 1, 0xf, 0xf, false));
+}
+
+struct HCursor { int j, ks, q, r; };
+
+template <bool kConv>
+__global__ __launch_bounds__(kHThreads, 3) void xdt_proj_bf16_kernel(XdtHArgs p) {
+  __shared__ __attribute__((aligned(16))) uint16_t sX[2][kHKS * kHXP];      // [d][t]
+  __shared__ __attribute__((aligned(16))) uint16_t sW[2][64 * kHWP];        // [s][d]
+  __shared__ __attribute__((aligned(16))) uint16_t sDt[kHTok * kHDP];       // [t][r] of the tile just finished
+  __shared__ __attribute__((aligned(16))) float sTap[kConv ? kHMaxDConv * 4 : 4];
+  __shared__ float sBias[kConv ? kHMaxDConv : 1];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, hh = lane >> 5;
+  const int sblk = wave & 1, tblk = wave >> 1;
+  const int D = p.D, L = p.L, S = p.S, R = p.R;
+  const int tps = __builtin_amdgcn_readfirstlane((L + kHTok - 1) / kHTok);
+  const int ntiles = p.batch * tps;
+  const int nwg = static_cast<int>(gridDim.x), wg = static_cast<int>(blockIdx.x);
+  const int ntw = __builtin_amdgcn_readfirstlane((ntiles - wg + nwg - 1) / nwg);
+  if (ntw <= 0) return;
+  const int nk = D / kHKS;                                 // even (host: D % 64 == 0)
+  const int ndb = D / 32;
+  const int nunits = wave < ndb ? 2 * ((ndb - wave + 3) / 4) : 0;
+  const int gq = __builtin_amdgcn_readfirstlane(nwg / tps), gr = nwg - gq * tps;
+  const unsigned sample_bytes = static_cast<unsigned>(D) * static_cast<unsigned>(L) * 2u;
+
+  for (int i = tid; i < kHTok * kHDP; i += kHThreads) sDt[i] = 0;
+  if (kConv) {
+    for (int d = tid; d < D; d += kHThreads) {
+      *reinterpret_cast<float4*>(&sTap[4 * d]) = *reinterpret_cast<const float4*>(p.cw + 4 * static_cast<size_t>(d));
+      sBias[d] = p.cb ? p.cb[d] : 0.f;
+    }
+  }
+  __syncthreads();
+
+  auto advance = [&](HCursor& c, int n) {
+    c.ks += n;
+    const bool wrap = c.ks >= nk;
+    c.ks -= wrap ? nk : 0;
+    c.j += wrap ? 1 : 0;
+    c.r += wrap ? gr : 0;
+    c.q += wrap ? gq : 0;
+    const bool carry = c.r >= tps;
+    c.r -= carry ? tps : 0;
+    c.q += carry ? 1 : 0;
+  };
+
+  // ---- staging identities: x tile 32 d x 64 t = 256 packs of 8; thread -> (d = tid >> 3, t8 = 8 (tid & 7)) -----------
+  const int xd = tid >> 3, xt = 8 * (tid & 7);
+  const bool first = (tid & 7) == 0;
+  const unsigned xoff = (static_cast<unsigned>(xd) * L + xt) * 2u;
+  // Wx tile 64 s x 32 d = 256 packs of 8; thread -> (s = tid >> 2, d8 = 8 (tid & 3))
+  const int ws = tid >> 2, wd = 8 * (tid & 3);
+  const unsigned woff = ws < S ? (static_cast<unsigned>(ws) * D + wd) * 2u : kHOob;
+  const hrsrc_t rs_wx = hmake_rsrc(p.wx, static_cast<unsigned>(S) * D * 2u);
+  const hrsrc_t rs_wdt = hmake_rsrc(p.wdt, static_cast<unsigned>(D) * R * 2u);
+
+  struct Stage { uint4 rx, rw, rh; };
+  struct Ops { uint4 a[2], b[2]; };
+
+  // Cursor fields enter descriptors and scalar offsets.  In the loop they live in SGPRs anyway; in the prologue hipcc
+  // had them in VGPRs, could not prove them uniform and wrapped those buffer loads in waterfall loops -- whose loads
+  // its s_waitcnt bookkeeping counts once although the counter sees every trip: the first conv read its neighbours'
+  // packs (DPP) before they had landed, on some workgroups, on some runs (tests/test_gpu_xdt_proj.py caught it on
+  // the bf16 form; the fp32 form had the same loops).  readfirstlane makes the uniformity explicit: no waterfall.
+  auto uniform = [](const HCursor& c) {                    // the same values, provably wave-uniform (SGPRs)
+    return HCursor{__builtin_amdgcn_readfirstlane(c.j), __builtin_amdgcn_readfirstlane(c.ks),
+                  __builtin_amdgcn_readfirstlane(c.q), __builtin_amdgcn_readfirstlane(c.r)};
+  };
+  auto issue = [&](Stage& st, const HCursor& c_) {
+    const HCursor c = uniform(c_);
+    const hrsrc_t rs = hmake_rsrc(p.x + static_cast<size_t>(c.q) * p.x_bs, c.j < ntw ? sample_bytes : 0u);
+    const int t0 = c.r * kHTok;
+    const unsigned soff = (static_cast<unsigned>(c.ks) * kHKS * L + t0) * 2u;
+    const bool xok = t0 + xt < L;                          // L % 8 == 0: a pack is all in or all out
+    st.rx = hload16(rs, xok ? xoff : kHOob, soff);
+    // the pack in front of the tile for the row's first lane (t0 > 0: soff >= 128, so soff - 16 does not wrap)
+    if (kConv) st.rh = hload16(rs, (first && t0 > 0) ? xoff : kHOob, soff - 16u);
+    st.rw = hload16(rs_wx, woff, static_cast<unsigned>(c.ks) * kHKS * 2u);
+  };
+  auto stage = [&](const Stage& st, const HCursor& c_, int buf) {
+    const HCursor c = uniform(c_);
+    uint4 v = st.rx;
+    if (kConv) {
+      const hrsrc_t rs_xc = hmake_rsrc(p.xconv + static_cast<size_t>(c.q) * D * L, c.j < ntw ? sample_bytes : 0u);
+      const int t0 = c.r * kHTok;
+      const unsigned soff = (static_cast<unsigned>(c.ks) * kHKS * L + t0) * 2u;
+      const bool xok = t0 + xt < L;
+      const int d = c.ks * kHKS + xd;
+      // the three steps in front of the pack: elements 5, 6, 7 of the neighbouring lane's pack (DPP on every lane,
+      // pinned in front of the select: xdt_proj.hip on why), the halo load for the row's first lane
+      unsigned qz = hdpp_prev(v.z), qw = hdpp_prev(v.w);
+      asm volatile("" : "+v"(qz), "+v"(qw));
+      const unsigned pz = first ? st.rh.z : qz, pw = first ? st.rh.w : qw;
+      const float win[11] = {hhi(pz), hlo(pw), hhi(pw), hlo(v.x), hhi(v.x), hlo(v.y), hhi(v.y),
+                             hlo(v.z), hhi(v.z), hlo(v.w), hhi(v.w)};
+      const float4 tp = *reinterpret_cast<const float4*>(&sTap[4 * d]);
+      const float w4[4] = {tp.x, tp.y, tp.z, tp.w};
+      const float bias = sBias[d];
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float acc = bias;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc = fmaf(w4[q], win[e + q], acc);
+        o[e] = acc * sigmoid_f(acc);
+      }
+      v = make_uint4(hpack(o[0], o[1]), hpack(o[2], o[3]), hpack(o[4], o[5]), hpack(o[6], o[7]));
+      hstore16(v, rs_xc, xok ? xoff : kHOob, soff);
+      if (!xok) v = make_uint4(0u, 0u, 0u, 0u);
+    }
+    *reinterpret_cast<uint4*>(&sX[buf][xd * kHXP + xt]) = v;
+    *reinterpret_cast<uint4*>(&sW[buf][ws * kHWP + wd]) = st.rw;
+  };
+  // operands of a step: MFMA j contracts d = 16 j + 8 hh + 0..7
+  auto read_ops = [&](Ops& o, int buf) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      o.a[j] = *reinterpret_cast<const uint4*>(&sW[buf][(sblk * 32 + li) * kHWP + 16 * j + 8 * hh]);
+      const uint16_t* col = &sX[buf][(16 * j + 8 * hh) * kHXP + tblk * 32 + li];
+      unsigned w[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        w[e] = static_cast<unsigned>(col[(2 * e) * kHXP]) | (static_cast<unsigned>(col[(2 * e + 1) * kHXP]) << 16);
+      o.b[j] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+  };
+
+  // ---- delta = Wdt @ dt of a finished tile, one (d-block, token block) unit at a time ------------------------------
+  uint4 wa[2];
+  // Wdt row of 2 R bytes: MFMA 0 takes r = 8 hh .. + 7, MFMA 1 r = 16 + 8 hh .. + 7 (past R: zeros)
+  unsigned wdoff[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) wdoff[j] = (16 * j + 8 * hh < R) ? (static_cast<unsigned>(li) * R + 16 * j + 8 * hh) * 2u : kHOob;
+  const unsigned dvoff = (static_cast<unsigned>(4 * hh) * L + li) * 2u;
+  auto wload = [&](int u_) {
+    const int u = __builtin_amdgcn_readfirstlane(u_);
+    const int db = wave + 4 * (u >> 1);
+    const unsigned soff = db < ndb ? static_cast<unsigned>(db) * 32u * R * 2u : 0u;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) wa[j] = hload16(rs_wdt, db < ndb ? wdoff[j] : kHOob, soff);
+  };
+  auto unit_mfma = [&](int u, f32x16& o) {
+    const uint16_t* dt = &sDt[((u & 1) * 32 + li) * kHDP + 8 * hh];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[i] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const uint4 b = *reinterpret_cast<const uint4*>(dt + 16 * j);
+      o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wa[j]), __builtin_bit_cast(bf16x8, b), o,
+                                                  0, 0, 0);
+    }
+  };
+  auto unit_store = [&](int u_, const f32x16& o, int q_, int r_) {
+    const int u = __builtin_amdgcn_readfirstlane(u_), q = __builtin_amdgcn_readfirstlane(q_),
+              r = __builtin_amdgcn_readfirstlane(r_);
+    const int db = wave + 4 * (u >> 1);
+    const hrsrc_t rs = hmake_rsrc(p.delta + static_cast<size_t>(q) * D * L, db < ndb ? sample_bytes : 0u);
+    const int tb0 = r * kHTok + (u & 1) * 32;
+    const unsigned voff = tb0 + li < L ? dvoff : kHOob;
+    const unsigned base = (static_cast<unsigned>(db) * 32u * L + tb0) * 2u;
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      hstore2(f32_to_bf16(o[i]), rs, voff, base + static_cast<unsigned>((i & 3) + 8 * (i >> 2)) * L * 2u);
+  };
+
+  // ---- the pipeline (same walk as the fp32 form) ---------------------------------------------------------------------
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  Stage s0, s1;
+  Ops o0;
+  // uniform values kept in SGPRs (integer division runs on the VALU): descriptors built from them are provably
+  // wave-uniform, no waterfall loop wraps the prologue's buffer loads and hipcc's vmcnt counts stay exact
+  const int q0 = __builtin_amdgcn_readfirstlane(wg / tps);
+  HCursor cm{0, 0, q0, wg - q0 * tps};
+  HCursor cr = cm, cs = cm, cl = cm;
+  advance(cr, 1);
+  advance(cs, 1); advance(cs, 1);
+  {
+    issue(s0, cm);
+    issue(s1, cr);
+    stage(s0, cm, 0);
+    issue(s0, cs);
+    stage(s1, cr, 1);
+    cl = cs; advance(cl, 1);
+    issue(s1, cl);
+    advance(cl, 1);
+    __syncthreads();
+    read_ops(o0, 0);
+    __syncthreads();
+  }
+  int pq = 0, pr = 0;
+  auto iteration = [&](Ops& cur, Stage& st, const int buf, auto odd_tag, auto units_tag) {
+    constexpr bool kOdd = decltype(odd_tag)::value, kUnits = decltype(units_tag)::value;
+    f32x16 o;
+    const int u = cm.ks >> 1;
+    if (kOdd && kUnits) unit_mfma(u, o);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, cur.a[j]),
+                                                    __builtin_bit_cast(bf16x8, cur.b[j]), acc, 0, 0, 0);
+    stage(st, cs, buf);
+    if (kOdd && kUnits) {
+      unit_store(u, o, pq, pr);
+      wload(u + 1);
+    }
+    issue(st, cl);
+    read_ops(cur, buf ^ 1);
+    advance(cm, 1); advance(cr, 1); advance(cs, 1); advance(cl, 1);
+    __syncthreads();
+  };
+  using T = std::true_type;
+  using F = std::false_type;
+  for (int j = 0; j < ntw; ++j) {
+    if (j == 0) {
+      for (int k = 0; k < nk; k += 2) {
+        iteration(o0, s0, 0, F{}, F{});
+        iteration(o0, s1, 1, T{}, F{});
+      }
+    } else {
+      wload(0);
+      for (int k = 0; k < nk; k += 2) {
+        iteration(o0, s0, 0, F{}, T{});
+        iteration(o0, s1, 1, T{}, T{});
+      }
+      for (int u = nk / 2; u < nunits; ++u) {              // ndb % 4 != 0: units past nk / 2
+        f32x16 o;
+        if (!(u & 1)) wload(u);
+        unit_mfma(u, o);
+        unit_store(u, o, pq, pr);
+      }
+      if (2 * ((ndb + 3) / 4) > nk / 2) __syncthreads();   // those units still read the dt image rewritten below
+    }
+    // ---- the tile is complete: x_dbl out (token-major, bf16), its ROUNDED dt rows into LDS, accumulator cleared ---------
+    // accumulator register r holds Y[s = sblk*32 + (r & 3) + 8 (r >> 2) + 4 hh][t = tblk*32 + li]
+    {
+      const int tile = wg + j * nwg;
+      const int b = tile / tps, t0 = (tile - b * tps) * kHTok;
+      pq = b; pr = tile - b * tps;
+      const int t = t0 + tblk * 32 + li;
+      uint16_t* row = p.xdbl + (static_cast<size_t>(b) * L + t) * S;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int s = sblk * 32 + 8 * g + 4 * hh;
+        const uint2 pk = make_uint2(hpack(acc[4 * g], acc[4 * g + 1]), hpack(acc[4 * g + 2], acc[4 * g + 3]));
+        if (t < L && s < S) *reinterpret_cast<uint2*>(row + s) = pk;        // S % 4 == 0
+        if (sblk == 0)                                                        // r = s: rows past R pad K with zeros
+          *reinterpret_cast<uint2*>(&sDt[(tblk * 32 + li) * kHDP + 8 * g + 4 * hh]) = s < R ? pk : make_uint2(0u, 0u);
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    }
+    __syncthreads();
+  }
+  for (int u = 0; u < nunits; ++u) {                       // tail: delta of the last tile
+    f32x16 o;
+    if (!(u & 1)) wload(u);
+    unit_mfma(u, o);
+    unit_store(u, o, pq, pr);
+  }
+}
+
+}  // namespace simamba
+
+using namespace simamba;
+
+// Host entry used by xdt_proj.hip's launchers for io_dtype == SIMAMBA_BF16 (same argument checks there).
+int xdt_launch_bf16(const void* x, const float* cw, const float* cb, const void* wx, const void* wdt, void* xconv,
+                    void* xdbl, void* delta, int batch, int D, int L, int S, int R, long long x_bs, bool conv,
+                    hipStream_t stream) {
+  XdtHArgs a{};
+  a.x = static_cast<const uint16_t*>(x); a.cw = cw; a.cb = cb; a.xconv = static_cast<uint16_t*>(xconv);
+  a.wx = static_cast<const uint16_t*>(wx); a.wdt = static_cast<const uint16_t*>(wdt);
+  a.xdbl = static_cast<uint16_t*>(xdbl); a.delta = static_cast<uint16_t*>(delta);
+  a.batch = batch; a.D = D; a.L = L; a.S = S; a.R = R; a.x_bs = x_bs;
+  const long long ntiles = static_cast<long long>(batch) * ((L + kHTok - 1) / kHTok);
+  long long g = ntiles;
+  if (ntiles > 768) {                                      // 3 workgroups per CU resident; even tile counts
+    long long per = (ntiles + 767) / 768;
+    while (ntiles % per) ++per;
+    g = ntiles / per;
+  }
+  if (conv)
+    hipLaunchKernelGGL(xdt_proj_bf16_kernel<true>, dim3(static_cast<unsigned>(g)), dim3(kHThreads), 0, stream, a);
+  else
+    hipLaunchKernelGGL(xdt_proj_bf16_kernel<false>, dim3(static_cast<unsigned>(g)), dim3(kHThreads), 0, stream, a);
+  return static_cast<int>(hipGetLastError());
+}

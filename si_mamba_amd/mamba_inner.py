@@ -79,19 +79,20 @@ def in_proj_fn(hidden, weight, bias=None):
 
 
 def xdt_proj_fused_ok(x, wx, wdt, conv=False):
-    """Shapes / dtypes the hand-written MFMA kernel takes (include/simamba.h); anything else runs the two library
-    GEMMs (and, with ``conv``, the separate conv kernel)."""
+    """Shapes / dtypes the hand-written MFMA kernels take (include/simamba.h; fp32 and bf16, weights in the
+    activations' type); anything else runs the two library GEMMs (and, with ``conv``, the separate conv kernel)."""
     S, D = wx.shape
     R = wdt.shape[1]
-    return (x.is_cuda and x.dtype == torch.float32 and wx.dtype == torch.float32 and wdt.dtype == torch.float32
-            and x.dim() == 3 and x.stride(2) == 1 and x.stride(1) == x.shape[2] and x.stride(0) % 4 == 0
-            and x.shape[1] == D and D % 64 == 0 and x.shape[2] % 4 == 0 and S % 4 == 0 and S <= 64
+    pack = 4 if x.dtype == torch.float32 else 8
+    return (x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and wx.dtype == x.dtype and wdt.dtype == x.dtype
+            and x.dim() == 3 and x.stride(2) == 1 and x.stride(1) == x.shape[2] and x.stride(0) % pack == 0
+            and x.shape[1] == D and D % 64 == 0 and x.shape[2] % pack == 0 and S % 4 == 0 and S <= 64
             and D * x.shape[2] * 4 < 2 ** 32 - 65536 and (not conv or D <= 1024)
             and R % 4 == 0 and 4 <= R <= 24 and S >= R and wdt.shape[0] == D and x.data_ptr() % 16 == 0)
 
 
 def xdt_proj_fwd(x, wx, wdt, conv=None):
-    """x (B, D, L) fp32 (batch-strided views allowed), wx (S, D), wdt (D, R) -> x_dbl (B, L, S) token-major, delta
+    """x (B, D, L) fp32 or bf16 (batch-strided views allowed), wx (S, D), wdt (D, R) -> x_dbl (B, L, S) token-major, delta
     (B, D, L).  ``conv=(w (D, 4) fp32, bias (D) or None, out (B, D, L))``: the causal depthwise conv1d + SiLU is applied
     to x on the way in and its result written to ``out``.  No autograd: called from inside MambaInnerFn.forward, whose
     backward differentiates the products itself."""
@@ -104,13 +105,13 @@ def xdt_proj_fwd(x, wx, wdt, conv=None):
     with torch.cuda.device(x.device), _lib.timed("xdt_proj_fwd", x.device):
         if conv is None:
             rc = lib.simamba_xdt_proj_fwd(x.data_ptr(), wxc.data_ptr(), wdc.data_ptr(), x_dbl.data_ptr(),
-                                          delta.data_ptr(), Bsz, D, L, S, R, _lib.F32, x.stride(0),
+                                          delta.data_ptr(), Bsz, D, L, S, R, _lib.dtype_code(x.dtype), x.stride(0),
                                           _lib.stream_ptr(x.device))
         else:
             cw, cb, out = conv
             rc = lib.simamba_conv_xdt_proj_fwd(x.data_ptr(), cw.data_ptr(), _lib.ptr(cb), wxc.data_ptr(), wdc.data_ptr(),
                                                out.data_ptr(), x_dbl.data_ptr(), delta.data_ptr(), Bsz, D, L, S, R,
-                                               _lib.F32, x.stride(0), _lib.stream_ptr(x.device))
+                                               _lib.dtype_code(x.dtype), x.stride(0), _lib.stream_ptr(x.device))
     _lib.check(rc, "simamba_xdt_proj_fwd")
     return x_dbl, delta
 

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_version_strerror_and_chunks():
     lib = _lib.load()
-    assert lib.simamba_abi_version() == 7
+    assert lib.simamba_abi_version() == 8
     assert lib.simamba_strerror(0) == b"ok"
     assert b"dstate" in lib.simamba_strerror(-4)
     assert lib.simamba_scan_num_chunks(64) == 1

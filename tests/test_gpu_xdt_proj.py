@@ -104,3 +104,76 @@ def test_conv_fused_into_the_staging_matches_the_conv_kernel(B, D, L, bias, devi
     want_dbl = torch.einsum("sd,bdt->bts", wx.cpu().double(), oc.double())
     assert nerr(x_dbl[sel], want_dbl) < 1e-5
     assert nerr(delta[sel], torch.einsum("dr,btr->bdt", wdt.cpu().double(), want_dbl[:, :, :R])) < 1e-5
+
+
+# ---- bf16 form (v_mfma_f32_32x32x16_bf16; the reference's autocast roundings) ---------------------------------------
+@pytest.mark.parametrize("B,D,L,N,R", [(2, 768, 1024, 16, 24), (3, 256, 72, 16, 8), (1, 768, 208, 16, 24),
+                                       (1, 64, 8, 16, 4), (64, 768, 1024, 16, 24), (40, 64, 1024, 16, 4),
+                                       (60, 192, 640, 16, 12), (130, 128, 616, 16, 8)])
+def test_xdt_proj_bf16_matches_rounded_products(B, D, L, N, R, device):
+    """bf16 operands: x_dbl is the float64 product of the bf16 values rounded once to bf16, delta the product of Wdt with
+    those ROUNDED dt rows, rounded once (what x_proj followed by dt_proj give under autocast).  1e-2 is the north-star
+    bar; the observed error is one bf16 rounding of values that sit on a rounding boundary."""
+    from si_mamba_amd.mamba_inner import xdt_proj_fused_ok, xdt_proj_fwd
+    S = R + 2 * N
+    g = torch.Generator().manual_seed(D + L + 1)
+    x = torch.randn(B, D, L, generator=g).bfloat16()
+    wx = (torch.randn(S, D, generator=g) / D ** 0.5).bfloat16()
+    wdt = (torch.randn(D, R, generator=g) / R ** 0.5).bfloat16()
+    xd, wxd, wdd = x.to(device), wx.to(device), wdt.to(device)
+    assert xdt_proj_fused_ok(xd, wxd, wdd)
+    x_dbl, delta = xdt_proj_fwd(xd, wxd, wdd)
+    assert x_dbl.dtype == torch.bfloat16 and delta.dtype == torch.bfloat16
+    sel = slice(None) if B <= 3 else torch.tensor([0, B // 2, B - 1])
+    want_dbl = torch.einsum("sd,bdt->bts", wx.double(), x[sel].double())
+    assert nerr(x_dbl[sel], want_dbl) < 1e-2
+    # delta from the kernel's own (rounded) dt rows: isolates the second product from the first one's rounding
+    want_delta = torch.einsum("dr,btr->bdt", wdt.double(), x_dbl[sel][:, :, :R].double().cpu())
+    assert nerr(delta[sel], want_delta) < 1e-2
+    # mean error well below one bf16 ulp of the scale: no systematic loss (a dropped K block would show here)
+    assert (x_dbl[sel].double().cpu() - want_dbl).abs().mean() < 4e-3 * want_dbl.abs().mean().clamp_min(1e-3)
+    assert (delta[sel].double().cpu() - want_delta).abs().mean() < 4e-3 * want_delta.abs().mean().clamp_min(1e-3)
+    x_dbl2, delta2 = xdt_proj_fwd(xd, wxd, wdd)
+    assert torch.equal(x_dbl, x_dbl2) and torch.equal(delta, delta2)
+
+
+@pytest.mark.parametrize("B,D,L", [(2, 768, 1024), (3, 256, 72), (1, 64, 8), (64, 768, 1024), (40, 64, 1024),
+                                   (60, 192, 616)])
+@pytest.mark.parametrize("bias", [True, False])
+def test_conv_fused_bf16_matches_the_conv_kernel(B, D, L, bias, device):
+    """bf16 conv-fused form: x_conv bit-identical to the stand-alone bf16 conv kernel (same fp32 fmaf chain, one rounding),
+    x_dbl / delta bit-identical to the unfused bf16 kernel run on that conv output."""
+    from si_mamba_amd import causal_conv1d_fn
+    from si_mamba_amd.mamba_inner import xdt_proj_fwd
+    N, R = 16, (24 if D == 768 else 8)
+    S = R + 2 * N
+    g = torch.Generator().manual_seed(L + 3)
+    xz = torch.randn(B, 2 * D, L, generator=g).bfloat16().to(device)
+    x_in = xz[:, :D]
+    cw = (torch.randn(D, 4, generator=g) * 0.5).to(device)
+    cb = torch.randn(D, generator=g).to(device) if bias else None
+    wx = (torch.randn(S, D, generator=g) / D ** 0.5).bfloat16().to(device)
+    wdt = (torch.randn(D, R, generator=g) / R ** 0.5).bfloat16().to(device)
+    x_conv = torch.empty(B, D, L, device=device, dtype=torch.bfloat16)
+    x_dbl, delta = xdt_proj_fwd(x_in, wx, wdt, conv=(cw, cb, x_conv))
+    want_conv = causal_conv1d_fn(x_in, cw, cb, "silu")
+    assert want_conv.dtype == torch.bfloat16 and torch.equal(x_conv, want_conv)
+    x_dbl2, delta2 = xdt_proj_fwd(want_conv, wx, wdt)
+    assert torch.equal(x_dbl, x_dbl2) and torch.equal(delta, delta2)
+
+
+def test_bf16_mixer_uses_the_fused_kernel(device, monkeypatch):
+    from si_mamba_amd import Mamba, mamba_inner
+    torch.manual_seed(0)
+    m = Mamba(384).to(device)
+    h = torch.randn(2, 256, 384, device=device)
+    calls = []
+    real = mamba_inner.xdt_proj_fwd
+    monkeypatch.setattr(mamba_inner, "xdt_proj_fwd", lambda *a, **k: (calls.append((a[0].dtype, k)), real(*a, **k))[1])
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        o1 = m(h)
+    assert calls and calls[0][0] == torch.bfloat16 and calls[0][1].get("conv") is not None
+    monkeypatch.setattr(mamba_inner, "xdt_proj_fused_ok", lambda *a, **k: False)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        o2 = m(h)
+    assert nerr(o1, o2) < 1e-2
