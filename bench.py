@@ -276,7 +276,9 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    _lib.enable_kernel_timing(not args.no_kernel_timing)
+    # events around the scan launches only (the roofline kernels): a pair of event records around every launch of the
+    # step costs 0.5 ms (fp32) to 7 ms (bf16, CPU-bound then) of the step it measures
+    _lib.enable_kernel_timing(not args.no_kernel_timing, only=("scan_fwd", "scan_bwd"))
     _lib._scan_variant[0] = args.scan_variant
     sync()
     t0 = time.perf_counter()
@@ -289,6 +291,14 @@ def main():
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = te.item()
     ktimes = _lib.kernel_times()
+    other = {}
+    if not args.no_kernel_timing:
+        # the other HIP kernels' mean durations, for the record: two more steps with every launch bracketed, untimed
+        _lib.enable_kernel_timing(True)
+        for _ in range(2):
+            step()
+        sync()
+        other = {k: v for k, v in _lib.kernel_times().items() if k not in ktimes}
     _lib.enable_kernel_timing(False)
     assert torch.isfinite(loss).item(), "non-finite loss in the timed region"
 
@@ -335,6 +345,8 @@ def main():
                                        "evens them out is 14 % faster alone, 15 % slower behind the 400 MB the "
                                        "preceding kernel has just written: DESIGN.md 4.1)"}
             out["kernels"] = {k: {"launches": v[0], "mean_ms": round(v[1], 4)} for k, v in ktimes.items()}
+            out["kernels_outside_timed_region"] = {k: {"launches": v[0], "mean_ms": round(v[1], 4)}
+                                                   for k, v in other.items()}
             if "scan_bwd" in ktimes:
                 bb = scan_bwd_bytes(args.batch, D, L, N, s)
                 nb, msb = ktimes["scan_bwd"]
