@@ -9,9 +9,11 @@ B=64 per GPU, 1024 points -> 128 patches, d=384, 12 blocks (Mamba L = 1024), one
 Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
   roofline      selective-scan forward kernel inside the timed region: algorithmic bytes per launch /
                 mean launch duration from events recorded on the launch stream, vs 8 TB/s HBM.
-  cpu_baseline  the oracle (CPU restatement) running the same step on a 2-cloud sample on the host cores.
-plus "headline_scan" (the north-star micro-shape B=256, L=128, D=768, N=16, measured after the timed
-region) and "kernels" (mean ms per launch of every HIP kernel in the timed region).
+  cpu_baseline  the oracle (CPU restatement) running the same step on a bounded sample (two steps of 4 clouds after a
+                warm-up step) on the host cores.
+plus "headline_scan" (the north-star micro-shape B=256, L=128, D=768, N=16, measured after the timed region, fp32 and
+bf16 I/O), "kernels" (mean ms per launch of the two scan kernels, event-bracketed inside the timed region) and
+"kernels_outside_timed_region" (the other HIP kernels, from two more steps after it).
 """
 from __future__ import annotations
 
