@@ -25,9 +25,16 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_sh
     step()
     torch.cuda.synchronize()
 cnt = collections.Counter()
-for e in prof.events():
-    if e.name in ("aten::zeros", "aten::zero_", "aten::fill_", "aten::zeros_like", "aten::new_zeros", "aten::full", "aten::ones_like", "aten::ones"):
-        st = [s for s in (e.stack or []) if "si_mamba_amd" in s or "bench" in s or "torch/nn" in s or "optim" in s or "autograd" in s]
-        cnt[(e.name, str(e.input_shapes)[:60], (st[0] if st else "?")[-90:])] += 1
-for k, v in cnt.most_common(40):
+ev = [e for e in prof.events()]
+cpu_ops = [e for e in ev if e.device_type == torch.autograd.DeviceType.CPU]
+for e in ev:
+    n = e.name
+    if e.device_type != torch.autograd.DeviceType.CPU:
+        continue
+    # top-level-ish ops that have kernels attached
+    for k in e.kernels:
+        kn = k.name
+        if "FillFunctor" in kn or "fillBuffer" in kn or "copyBuffer" in kn or "direct_copy" in kn or "neg_kernel" in kn or "exp_kernel" in kn:
+            cnt[(kn[:60], n, str(e.input_shapes)[:70])] += 1
+for k, v in cnt.most_common(45):
     print(v, k)
