@@ -160,6 +160,16 @@ class MixerModel(nn.Module):
         residual = torch.gather(res0, 1, token_index.unsqueeze(-1).expand(-1, -1, res0.shape[-1]))
         return hidden, residual
 
+    def _precompute_A(self):
+        """A = -exp(A_log) of every layer in three launches (stack, exp, neg) instead of two per layer, and one
+        exp / neg backward for all of them; each mixer picks its slice up in forward_xz (mamba_simple.py)."""
+        mixers = [layer.mixer for layer in self.layers]
+        if (len(mixers) > 1 and all(type(m) is Mamba for m in mixers) and mixers[0].A_log.is_cuda
+                and all(m.A_log.shape == mixers[0].A_log.shape for m in mixers)):
+            A_all = -torch.exp(torch.stack([m.A_log for m in mixers]).float())
+            for m, A in zip(mixers, A_all.unbind(0)):
+                m._A_pre = A
+
     def forward(self, input_ids, pos, inference_params=None, token_index=None):
         """Reference signature (models/point_mamba.py:247).  ``token_index`` (B, L) int64, optional and specific to
         this implementation: when given, ``input_ids`` / ``pos`` are the G DISTINCT tokens (B, G, C) and the sequence
@@ -167,6 +177,7 @@ class MixerModel(nn.Module):
         per-token head runs on G tokens instead of L."""
         first = 0
         residual = None
+        self._precompute_A()
         if token_index is not None:
             done = (self._first_block_on_distinct_tokens(input_ids, pos, token_index)
                     if inference_params is None else None)

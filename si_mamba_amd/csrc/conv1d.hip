@@ -237,9 +237,11 @@ extern "C" int simamba_causal_conv1d_bwd(const void* x, const float* w, const fl
   if (rc) return rc;
   if (!dout || !dx || !dw) return SIMAMBA_E_NULLPTR;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  hipError_t e = hipMemsetAsync(dw, 0, sizeof(float) * dim * width, s);
+  // the two accumulators are zeroed here; a caller that carves dbias directly behind dw gets one memset node
+  const bool joined = dbias == dw + static_cast<size_t>(dim) * width;
+  hipError_t e = hipMemsetAsync(dw, 0, sizeof(float) * (static_cast<size_t>(dim) * width + (joined ? dim : 0)), s);
   if (e != hipSuccess) return static_cast<int>(e);
-  if (dbias) {
+  if (dbias && !joined) {
     e = hipMemsetAsync(dbias, 0, sizeof(float) * dim, s);
     if (e != hipSuccess) return static_cast<int>(e);
   }

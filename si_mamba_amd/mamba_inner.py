@@ -231,8 +231,10 @@ class MambaInnerFn(torch.autograd.Function):
         # dt_proj / x_proj
         dx_dbl = torch.empty(Bsz, L, S, device=dev, dtype=io)
         dx_dbl[:, :, :R].copy_(_xw(ddelta.transpose(1, 2), dtw_c))
-        dx_dbl[:, :, R:R + N].copy_(dB.transpose(1, 2))
-        dx_dbl[:, :, R + N:].copy_(dC.transpose(1, 2))
+        # dB | dC (two adjacent (B, N, L) blocks of the accumulator allocation, _lib.scan_bwd_accumulators) into the
+        # token-major columns [R, S) in one strided copy
+        dBC = torch.as_strided(dB, (2, Bsz, N, L), (Bsz * N * L, N * L, L, 1))
+        dx_dbl[:, :, R:].view(Bsz, L, 2, N).copy_(dBC.permute(1, 3, 0, 2))
         d_dt_w = _sum_bmm(ddelta, x_dbl[:, :, :R])                                     # (D, R)
         d_x_w = _sum_bmm(dx_dbl.transpose(1, 2), x_conv.transpose(1, 2))               # (S, D)
         # dx_conv = du + x_proj_w^T @ dx_dbl^T, accumulated in place by the GEMM (beta = 1)
@@ -240,8 +242,10 @@ class MambaInnerFn(torch.autograd.Function):
         torch.baddbmm(du, wxT, dx_dbl.transpose(1, 2), out=du)
 
         # conv1d: dx goes straight into the first half of dxz
-        dcw = torch.empty_like(cw)
-        dcb = torch.empty(Dm, **f32) if cb is not None else None
+        # taps and bias gradients carved from one allocation: the library clears adjacent accumulators with one memset
+        dconv = torch.empty(Dm * W + (Dm if cb is not None else 0), **f32)
+        dcw = dconv[:Dm * W].view(Dm, W)
+        dcb = dconv[Dm * W:] if cb is not None else None
         with torch.cuda.device(dev), _lib.timed("conv1d_bwd", dev):
             rc = lib.simamba_causal_conv1d_bwd(xz.data_ptr(), cw.data_ptr(), _lib.ptr(cb), du.data_ptr(),
                                                dxz.data_ptr(), dcw.data_ptr(), _lib.ptr(dcb),

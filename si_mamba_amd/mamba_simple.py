@@ -84,10 +84,12 @@ class Mamba(nn.Module):
                 "step-wise decoding caches are not on the SI-Mamba path (no reference runner passes "
                 "inference_params; models/block.py:75-76 is never reached)")
         batch, seqlen, _ = hidden_states.shape
-        A = -torch.exp(self.A_log.float())
         # (2D, d) @ (B, d, L) -> (B, 2D, L): L is the contiguous axis the HIP kernels stream along
         if self.use_fast_path:
             return self.forward_xz(self.in_proj_xz(hidden_states))
+        A = self.__dict__.pop("_A_pre", None)
+        if A is None:
+            A = -torch.exp(self.A_log.float())
         # reference composition of the separate ops (same kernels; torch.matmul / chunk copy the views)
         xz = torch.matmul(self.in_proj.weight, hidden_states.transpose(1, 2))
         if self.in_proj.bias is not None:
@@ -113,7 +115,9 @@ class Mamba(nn.Module):
         activation-sized copies (mamba_inner.py).  forward(h) == forward_xz(in_proj_xz(h)); MixerModel calls the two
         halves separately for the first block when the sequence is an expansion of fewer distinct tokens
         (seq_expand.py)."""
-        A = -torch.exp(self.A_log.float())
+        A = self.__dict__.pop("_A_pre", None)               # MixerModel computes -exp(A_log) of all its layers at once
+        if A is None:
+            A = -torch.exp(self.A_log.float())
         return mamba_inner_fn(xz, self.conv1d.weight, self.conv1d.bias, self.x_proj.weight,
                               self.dt_proj.weight, self.out_proj.weight, self.out_proj.bias, A,
                               self.D.float(), delta_bias=self.dt_proj.bias.float(),

@@ -24,17 +24,26 @@ torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=True) as prof:
     step()
     torch.cuda.synchronize()
+# kernel-side view: for every fill kernel, the innermost CPU op whose time range covers the launch (correlated by the
+# launch call's timestamp when the profiler lost the link)
+ev = list(prof.events())
+cpu = sorted([e for e in ev if e.device_type == torch.autograd.DeviceType.CPU], key=lambda e: e.time_range.start)
+import bisect
+starts = [e.time_range.start for e in cpu]
 cnt = collections.Counter()
-ev = [e for e in prof.events()]
-cpu_ops = [e for e in ev if e.device_type == torch.autograd.DeviceType.CPU]
-for e in ev:
-    n = e.name
-    if e.device_type != torch.autograd.DeviceType.CPU:
-        continue
-    # top-level-ish ops that have kernels attached
-    for k in e.kernels:
-        kn = k.name
-        if "FillFunctor" in kn or "fillBuffer" in kn or "copyBuffer" in kn or "direct_copy" in kn or "neg_kernel" in kn or "exp_kernel" in kn:
-            cnt[(kn[:60], n, str(e.input_shapes)[:70])] += 1
-for k, v in cnt.most_common(45):
+launches = [e for e in cpu if e.name in ("hipLaunchKernel", "hipExtModuleLaunchKernel", "hipModuleLaunchKernel", "hipMemsetAsync", "hipMemcpyAsync")]
+print("launch calls:", collections.Counter(e.name for e in launches))
+def innermost(t, tid):
+    best = None
+    i = bisect.bisect_right(starts, t)
+    for e in reversed(cpu[max(0, i - 400):i]):
+        if e.thread == tid and e.time_range.start <= t <= e.time_range.end and not e.name.startswith("hip"):
+            if best is None or (e.time_range.end - e.time_range.start) < (best.time_range.end - best.time_range.start):
+                best = e
+    return best
+for l in launches:
+    if l.name == "hipMemsetAsync" or any("FillFunctor" in k.name for k in l.kernels):
+        par = innermost(l.time_range.start, l.thread)
+        cnt[(l.name, par.name if par else "?", str(par.input_shapes)[:60] if par else "")] += 1
+for k, v in cnt.most_common(30):
     print(v, k)
