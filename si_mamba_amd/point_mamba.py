@@ -21,6 +21,7 @@ import torch.nn as nn
 
 from . import grouping, spectral
 from .block import MixerModel
+from .add_norm import add_layer_norm_fn
 from .encoder_ops import bn_relu_fn, group_max_fn, token_linear
 
 
@@ -253,7 +254,12 @@ class PointMamba(nn.Module):
             x, pos = self.order_tokens(tokens, pos, center, order)
             x = self.drop_out(x)
             x = self.blocks(x, pos)
-        x = self.norm(x)
+        if x.is_cuda and type(self.norm) is nn.LayerNorm and x.dim() == 3:
+            # the same LayerNorm through the one-pass kernels of add_norm.py (no residual: nothing is added or copied)
+            x = add_layer_norm_fn(x, None, self.norm.weight, self.norm.bias, self.norm.eps,
+                                  out_dtype=self.norm.weight.dtype)[0]
+        else:
+            x = self.norm(x)
         ret = self.cls_head_finetune(x.mean(1))
         if not want_policy:
             return ret
