@@ -36,3 +36,17 @@ for K2 in (384, 1152, 2304):
     a = torch.randn(M, K2, device=dev, dtype=torch.bfloat16); b = torch.randn(N, K2, device=dev, dtype=torch.bfloat16)
     t = timeit(lambda: torch.mm(a, b.t()))
     print(f"bf16 mm (bf16 out) M={M} K={K2} N={N}: {t:.1f} us = {2*M*K2*N/t*1e-6:.0f} TF/s")
+
+# fp16 pieces (11-bit mantissa each: two pieces carry 22 bits), per-tensor power-of-two scaling against underflow
+def split2h(a):
+    s = 2.0 ** torch.floor(torch.log2(1.0 / a.abs().max())).item()
+    a = a * s
+    hi = a.half(); lo = (a - hi.float()).half()
+    return hi, lo, s
+xh, xl, sx = split2h(x); wh, wl, sw = split2h(w)
+A3 = torch.cat([xh, xh, xl], 1).contiguous(); B3 = torch.cat([wh, wl, wh], 1).contiguous()
+o = torch.mm(A3, B3.t(), out_dtype=torch.float32) / (sx * sw)
+t = timeit(lambda: torch.mm(A3, B3.t(), out_dtype=torch.float32))
+print(f"fp16 split, 2 pieces / 3 products: K'={A3.shape[1]} {t:.1f} us  err {((o - ref).abs().max() / ref.abs().max()).item():.2e}")
+ts = timeit(lambda: split2h(x))
+print(f"split of x with torch ops: {ts:.1f} us")
