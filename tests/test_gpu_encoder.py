@@ -130,3 +130,36 @@ def test_bn_relu_argument_errors(device):
     rc = lib.simamba_bn_relu_fwd(x.data_ptr(), None, 0, None, None, None, None, 0.1, 1e-5, 1, x.data_ptr(),
                                  m.data_ptr(), m.data_ptr(), part.data_ptr(), 64, 8, 4, 0, None)
     assert rc < 0
+
+
+@pytest.mark.parametrize("rows,cin,cout,bias", [(262144, 256, 512, False), (65536, 128, 256, True), (32768, 3, 128, True),
+                                                (1000, 64, 32, True)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_token_linear_matches_linear(rows, cin, cout, bias, dtype, device):
+    """token_linear: F.linear's forward, and a weight gradient formed as a split-K batched product over 64 row slabs
+    (fp32 partials) instead of one K = rows GEMM -- same gradients as autograd's F.linear (to the rounding of a
+    different summation order; under autocast the reference path rounds dW to bf16, this one does not).
+    (1000 rows: below the slab size, the plain product.)"""
+    from si_mamba_amd.encoder_ops import token_linear
+    g = torch.Generator().manual_seed(rows + cin)
+    x = torch.randn(rows, cin, generator=g).to(device)
+    w = (torch.randn(cout, cin, generator=g) / cin ** 0.5).to(device)
+    b = torch.randn(cout, generator=g).to(device) if bias else None
+    dy = torch.randn(rows, cout, generator=g).to(device)
+    grads = {}
+    for name, fn in (("ours", token_linear), ("torch", torch.nn.functional.linear)):
+        xa, wa = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        ba = None if b is None else b.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=(dtype == torch.bfloat16)):
+            y = fn(xa, wa, ba)
+        assert y.dtype == dtype
+        y.backward(dy.to(dtype))
+        grads[name] = (y.detach(), xa.grad, wa.grad, None if ba is None else ba.grad)
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    assert torch.equal(grads["ours"][0], grads["torch"][0])                    # the forward IS F.linear
+    for got, want in zip(grads["ours"][1:], grads["torch"][1:]):
+        if want is not None:
+            assert got.dtype == want.dtype and nerr(got, want) < tol
+    if dtype == torch.float32:                                                 # and against float64 for the weight gradient
+        want = dy.double().t() @ x.double()
+        assert nerr(grads["ours"][2], want) < 1e-5
