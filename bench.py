@@ -138,20 +138,28 @@ def headline_scan(device, iters=30):
     out = torch.empty_like(d["u"])
     du, dd, dz = (torch.empty_like(d["u"]) for _ in range(3))
     acc = _lib.scan_bwd_accumulators(B, D, L, N, True, True, device)
+    # the forward is timed without checkpoints (the north-star figure: what an inference call runs); the backward
+    # reads the checkpoints of one untimed forward in the layout the library picks for this shape
+    ck_step = lib.simamba_scan_ckpt_step(B, D, L, N, 0)
+    nck = lib.simamba_scan_ckpt_floats(B, D, L, N, ck_step)
+    ck = torch.empty(nck, device=device) if nck else None
+    ck16 = None
 
-    def fwd():
+    def fwd(ckpt=None):
         return lib.simamba_selective_scan_fwd(d["u"].data_ptr(), d["delta"].data_ptr(), d["A"].data_ptr(),
                                               d["B"].data_ptr(), d["C"].data_ptr(), d["D"].data_ptr(), d["z"].data_ptr(),
-                                              d["delta_bias"].data_ptr(), out.data_ptr(), None, None, B, D, L, N, 0, 1,
-                                              0, 0, 0, 0, 0, st)
+                                              d["delta_bias"].data_ptr(), out.data_ptr(), _lib.ptr(ckpt), None,
+                                              B, D, L, N, 0, 1, 0, 0, 0, 0, ck_step, 0, st)
 
     def bwd():
         return lib.simamba_selective_scan_bwd(d["u"].data_ptr(), d["delta"].data_ptr(), d["A"].data_ptr(),
                                               d["B"].data_ptr(), d["C"].data_ptr(), d["D"].data_ptr(), d["z"].data_ptr(),
-                                              d["delta_bias"].data_ptr(), d["dout"].data_ptr(), None, du.data_ptr(),
-                                              dd.data_ptr(), acc[0].data_ptr(), acc[1].data_ptr(), acc[2].data_ptr(),
-                                              acc[3].data_ptr(), dz.data_ptr(), acc[4].data_ptr(), B, D, L, N, 0, 1,
-                                              0, 0, 0, 0, 0, st)
+                                              d["delta_bias"].data_ptr(), d["dout"].data_ptr(), _lib.ptr(ck),
+                                              du.data_ptr(), dd.data_ptr(), acc[0].data_ptr(), acc[1].data_ptr(),
+                                              acc[2].data_ptr(), acc[3].data_ptr(), dz.data_ptr(), acc[4].data_ptr(),
+                                              B, D, L, N, 0, 1, 0, 0, 0, 0, 0, ck_step, st)
+
+    assert fwd(ck) == 0
 
     for mode, fn in (("fwd", fwd), ("bwd", bwd)):
         for _ in range(5):
@@ -172,19 +180,25 @@ def headline_scan(device, iters=30):
     outh = torch.empty_like(h["u"])
     duh, ddh, dzh = (torch.empty_like(h["u"]) for _ in range(3))
 
-    def fwd16():
+    ck_step16 = lib.simamba_scan_ckpt_step(B, D, L, N, _lib.BF16)
+    nck16 = lib.simamba_scan_ckpt_floats(B, D, L, N, ck_step16)
+    ck16 = torch.empty(nck16, device=device) if nck16 else None
+
+    def fwd16(ckpt=None):
         return lib.simamba_selective_scan_fwd(h["u"].data_ptr(), h["delta"].data_ptr(), d["A"].data_ptr(),
                                               h["B"].data_ptr(), h["C"].data_ptr(), d["D"].data_ptr(), h["z"].data_ptr(),
-                                              d["delta_bias"].data_ptr(), outh.data_ptr(), None, None, B, D, L, N,
-                                              _lib.BF16, 1, 0, 0, 0, 0, 0, st)
+                                              d["delta_bias"].data_ptr(), outh.data_ptr(), _lib.ptr(ckpt), None,
+                                              B, D, L, N, _lib.BF16, 1, 0, 0, 0, 0, ck_step16, 0, st)
 
     def bwd16():
         return lib.simamba_selective_scan_bwd(h["u"].data_ptr(), h["delta"].data_ptr(), d["A"].data_ptr(),
                                               h["B"].data_ptr(), h["C"].data_ptr(), d["D"].data_ptr(), h["z"].data_ptr(),
-                                              d["delta_bias"].data_ptr(), h["dout"].data_ptr(), None, duh.data_ptr(),
-                                              ddh.data_ptr(), acc[0].data_ptr(), acc[1].data_ptr(), acc[2].data_ptr(),
-                                              acc[3].data_ptr(), dzh.data_ptr(), acc[4].data_ptr(), B, D, L, N,
-                                              _lib.BF16, 1, 0, 0, 0, 0, 0, st)
+                                              d["delta_bias"].data_ptr(), h["dout"].data_ptr(), _lib.ptr(ck16),
+                                              duh.data_ptr(), ddh.data_ptr(), acc[0].data_ptr(), acc[1].data_ptr(),
+                                              acc[2].data_ptr(), acc[3].data_ptr(), dzh.data_ptr(), acc[4].data_ptr(),
+                                              B, D, L, N, _lib.BF16, 1, 0, 0, 0, 0, 0, ck_step16, st)
+
+    assert fwd16(ck16) == 0
 
     res["bf16_io"] = {}
     for mode, fn in (("fwd", fwd16), ("bwd", bwd16)):

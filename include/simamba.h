@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define SIMAMBA_ABI_VERSION 8
+#define SIMAMBA_ABI_VERSION 9
 
 #define SIMAMBA_F32  0
 #define SIMAMBA_BF16 1
@@ -66,12 +66,29 @@ extern "C" {
 /* timesteps per scan chunk; simamba_scan_num_chunks(L) = ceil(L / chunk) */
 #define SIMAMBA_SCAN_CHUNK 128
 
+/*
+ * State checkpoints handed from the forward to the backward (`x_ckpt`, `ckpt_step` of both calls; 0 = _ROW):
+ *   SIMAMBA_SCAN_CKPT_ROW  (batch, dim, nchunks, dstate): state at the end of every 128-step chunk; written by every
+ *                          forward kernel, read by the row-scan backward (any shape).
+ *   SIMAMBA_SCAN_CKPT_SEQ  (batch, ceil(seqlen / 16), dim, 16): state after every 16th step; written by the
+ *                          lanes-per-channel forward kernels, read by the sequential backward (dstate == 16,
+ *                          dim % 64 == 0, delta_softplus, 16-byte aligned rows and B / C packs, tensors below 2^30
+ *                          elements; anything else returns SIMAMBA_E_VARIANT).
+ * simamba_scan_ckpt_step() is the library's own choice for a shape (host arithmetic only; the caller still has to
+ * meet the alignment rules above or pass _ROW); simamba_scan_ckpt_floats() the size of x_ckpt in floats (0: none
+ * needed, x_ckpt may be NULL).
+ */
+#define SIMAMBA_SCAN_CKPT_ROW 128
+#define SIMAMBA_SCAN_CKPT_SEQ 16
+
 int         simamba_abi_version(void);
 const char* simamba_strerror(int rc);           /* host string, static storage */
 int         simamba_scan_num_chunks(int seqlen);
 /* the forward kernel SIMAMBA_SCAN_AUTO picks for (batch, dim) when the operands qualify for all of them (one of the
  * SIMAMBA_SCAN_* values below; host-side arithmetic only, no GPU work): what a profile's kernel name should be */
 int         simamba_scan_fwd_auto_variant(int batch, int dim);
+int         simamba_scan_ckpt_step(int batch, int dim, int seqlen, int dstate, int io_dtype);
+long long   simamba_scan_ckpt_floats(int batch, int dim, int seqlen, int dstate, int ckpt_step);
 
 /*
  * Selective scan forward.
@@ -81,8 +98,9 @@ int         simamba_scan_fwd_auto_variant(int batch, int dim);
  *                      + t*bc_tstride (all three 0 => contiguous (batch, dstate, seqlen))
  *   z_bstride        : elements between consecutive batch samples of z (0 => dim*seqlen)
  *   D, delta_bias    : (dim) fp32, may be NULL
- *   x_ckpt           : (batch, dim, nchunks, dstate) fp32 or NULL.  State at the END of every
- *                      chunk; required by the backward when nchunks > 1.
+ *   x_ckpt, ckpt_step: state checkpoints for the backward (layouts above) or NULL: required by the backward
+ *                      when simamba_scan_ckpt_floats() > 0.  With _SEQ the forward runs a lanes-per-channel kernel
+ *                      (SIMAMBA_E_VARIANT if the operands cannot take one or `variant` names the row-scan kernel).
  *   last_state       : (batch, dim, dstate) fp32 or NULL.
  *   variant          : SIMAMBA_SCAN_AUTO in production: the library picks the kernel from the shape (no
  *                      environment variables, no global state).  The explicit values select one kernel for
@@ -105,11 +123,12 @@ int simamba_selective_scan_fwd(const void* u, const void* delta, const float* A,
                                float* last_state, int batch, int dim, int seqlen, int dstate,
                                int io_dtype, int delta_softplus, long long z_bstride,
                                long long bc_bstride, long long bc_nstride, long long bc_tstride,
-                               int variant, void* stream);
+                               int ckpt_step, int variant, void* stream);
 
 /*
- * Selective scan backward.  Inputs as forward (+ dout, x_ckpt from the forward when
- * nchunks > 1).  du, ddelta, dz : io_dtype (dz NULL iff z NULL).
+ * Selective scan backward.  Inputs as forward (+ dout, and x_ckpt / ckpt_step exactly as given to the
+ * forward; ckpt_step selects the kernel: _ROW the row-scan backward, _SEQ the sequential one).
+ * du, ddelta, dz : io_dtype (dz NULL iff z NULL).
  * dA (dim,dstate), dB, dC (batch,dstate,seqlen), dD, ddelta_bias (dim): fp32; the library
  * zeroes them on `stream` and then accumulates (float atomics: last-bit run-to-run jitter).
  * Not one byte outside these five spans is written: spans that are exactly adjacent in memory
@@ -125,7 +144,7 @@ int simamba_selective_scan_bwd(const void* u, const void* delta, const float* A,
                                int batch, int dim, int seqlen, int dstate,
                                int io_dtype, int delta_softplus, long long z_bstride,
                                long long dz_bstride, long long bc_bstride, long long bc_nstride,
-                               long long bc_tstride, void* stream);
+                               long long bc_tstride, int ckpt_step, void* stream);
 
 /*
  * Fused x_proj -> dt_proj of the mixer on the matrix cores (the two skinny GEMMs between the conv and the scan

@@ -15,11 +15,14 @@ Parity status (see DESIGN.md "Oracle"):
     restatement of their published algorithm is **parity unpinned** by the
     reference; it is cross-checked against an independent float64 closed-form
     summation (tests/test_oracle_scan.py).
-  * spectral ordering: restated from reference models/point_mamba.py:620-841
-    and executed with the same stock ``torch.linalg.eigh`` / ``topk`` /
-    ``sort`` calls the reference makes (CPU, LAPACK).  The reference has no
-    fixtures for it either: **parity unpinned**, but the library calls are
-    the reference's own.
+  * spectral ordering, token assembly (SAST / HLT), Block / MixerModel / create_block / _init_weights:
+    **pinned to the reference's own code.**  ``oracle/pin_from_reference.py`` reads
+    /root/reference/models/point_mamba.py (:115-272, :620-841, :889-898, :982-989, :1059-1112) and models/block.py
+    (:17-76) at run time, compiles those definitions unmodified (``device='cuda'`` mapped to the CPU) and stores
+    what they return in tests/golden/ref_*.npz.  tests/test_oracle_pinned.py holds this package to them (adjacency,
+    orders, index maps, block data flow: bit for bit; eigenpairs: bit for bit on the LAPACK configuration that
+    generated them, 3e-6 otherwise); tests/test_gpu_pinned.py and tests/test_gpu_spectral.py hold the HIP path to
+    the same files.  The mixer INSIDE those blocks is still this package's restatement (previous item).
   * state-dict contract: pinned by the parameter table in the reference's
     ``logs/finetuned_hardest.log:100-426`` (tests/golden/param_table_*.json).
 """

@@ -24,23 +24,27 @@ SPEC_SIGMA_MEAN = 0x20
 
 # forward-scan kernel selection (include/simamba.h): AUTO in production, the others for benchmarks / parity tests
 SCAN_AUTO, SCAN_ROWSCAN, SCAN_LPC2, SCAN_LPC4, SCAN_MIX = 0, 1, 2, 4, 6
+# checkpoint layouts handed from the forward scan to the backward (= which backward kernel runs)
+CKPT_ROW, CKPT_SEQ = 128, 16
 
 # name -> (restype, argtypes); mirrors include/simamba.h one to one
 _P = c_void_p
 _LL = c_longlong
-ABI_VERSION = 8
+ABI_VERSION = 9
 SIGNATURES = {
     "simamba_abi_version": (c_int, []),
     "simamba_strerror": (c_char_p, [c_int]),
     "simamba_scan_num_chunks": (c_int, [c_int]),
     "simamba_scan_fwd_auto_variant": (c_int, [c_int, c_int]),
+    "simamba_scan_ckpt_step": (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    "simamba_scan_ckpt_floats": (_LL, [c_int, c_int, c_int, c_int, c_int]),
     "simamba_selective_scan_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                            c_int, c_int, c_int, c_int, c_int, c_int,
-                                           _LL, _LL, _LL, _LL, c_int, _P]),
+                                           _LL, _LL, _LL, _LL, c_int, c_int, _P]),
     "simamba_selective_scan_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                            _P, _P, _P, _P, _P, _P, _P, _P,
                                            c_int, c_int, c_int, c_int, c_int, c_int,
-                                           _LL, _LL, _LL, _LL, _LL, _P]),
+                                           _LL, _LL, _LL, _LL, _LL, c_int, _P]),
     "simamba_xdt_proj_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _LL, _P]),
     "simamba_conv_xdt_proj_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _LL,
                                           _P]),
@@ -200,6 +204,44 @@ class scan_variant:
 
 def current_scan_variant():
     return _scan_variant[0]
+
+
+_scan_ckpt = [0]
+
+
+class scan_ckpt:
+    """Context manager for benchmarks and parity tests: the checkpoint layout (CKPT_ROW / CKPT_SEQ, i.e. the backward
+    kernel) the Python ops request instead of the library's own choice.  Production code never enters it."""
+
+    def __init__(self, step):
+        self.v, self.prev = int(step), None
+
+    def __enter__(self):
+        self.prev, _scan_ckpt[0] = _scan_ckpt[0], self.v
+        return self
+
+    def __exit__(self, *exc):
+        _scan_ckpt[0] = self.prev
+        return False
+
+
+def scan_plan(batch, dim, seqlen, dstate, dtype, aligned, device, need_grad):
+    """(ckpt_step, x_ckpt or None) for one forward / backward pair.  ``aligned``: the caller's statement that every
+    activation operand is 16-byte aligned with pack-aligned strides (what the sequential backward needs; the library
+    checks again and refuses otherwise)."""
+    import torch
+    lib = load()
+    code = dtype_code(dtype)
+    step = _scan_ckpt[0] or lib.simamba_scan_ckpt_step(batch, dim, seqlen, dstate, code)
+    if step == CKPT_SEQ and not (aligned and dstate == 16 and dim % 64 == 0 and
+                                 seqlen % (4 if code == F32 else 8) == 0):
+        step = CKPT_ROW
+    if _scan_variant[0] == SCAN_ROWSCAN:
+        step = CKPT_ROW                 # an explicit row-scan forward writes 128-step checkpoints only
+    if not need_grad:
+        return step, None
+    n = lib.simamba_scan_ckpt_floats(batch, dim, seqlen, dstate, step)
+    return step, (torch.empty(n, device=device, dtype=torch.float32) if n else None)
 
 
 def scan_bwd_accumulators(batch, dim, seqlen, dstate, has_D, has_bias, device):

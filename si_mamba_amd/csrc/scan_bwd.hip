@@ -10,61 +10,9 @@
 //   dA, dD, ddelta_bias (sum over time and batch): DPP row all-reduce -> one atomic per row.
 // Algorithmic HBM bytes: 7*B*D*L*s + 2*B*N*L*(s+4) + small.
 #include "scan_common.h"
+#include "scan_xlane.h"
 
 namespace simamba {
-
-// x[i] <- (x[i] + y[i]) after exchanging half of the lanes: lanes 0-31 end with the sum over halves of x,
-// lanes 32-63 with that of y (swap32); rows 0/2 with x summed over row pairs, rows 1/3 with y (swap16).
-// Inline asm on purpose: with ROCm 7.2's hipcc the two-result builtin
-// (__builtin_amdgcn_permlane{16,32}_swap) followed by r[0] + r[1] is register-coalesced into
-// "v_add v, v, v" (2 * r[0]); verified in the .s and on hardware (tools/permlane_probe.hip).
-// The s_nop pads cover the VALU-write -> permlane-swap read hazard, which hipcc does not see in asm.
-// One reduction stage for N register pairs: all N swaps go out back to back inside ONE asm block (they touch
-// disjoint registers, so only the block's inputs and outputs need the hazard padding), then N adds.
-template <int N>
-__device__ __forceinline__ void swap32_stage(float* x, float* y) {
-  static_assert(N == 8 || N == 4, "pairs per stage");
-  if constexpr (N == 8) {
-    asm volatile(
-        "s_nop 1\n\t"
-        "v_permlane32_swap_b32 %0, %8\n\tv_permlane32_swap_b32 %1, %9\n\t"
-        "v_permlane32_swap_b32 %2, %10\n\tv_permlane32_swap_b32 %3, %11\n\t"
-        "v_permlane32_swap_b32 %4, %12\n\tv_permlane32_swap_b32 %5, %13\n\t"
-        "v_permlane32_swap_b32 %6, %14\n\tv_permlane32_swap_b32 %7, %15\n\t"
-        "s_nop 1"
-        : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]),
-          "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]), "+v"(y[4]), "+v"(y[5]), "+v"(y[6]), "+v"(y[7]));
-  } else {
-    asm volatile(
-        "s_nop 1\n\t"
-        "v_permlane32_swap_b32 %0, %4\n\tv_permlane32_swap_b32 %1, %5\n\t"
-        "v_permlane32_swap_b32 %2, %6\n\tv_permlane32_swap_b32 %3, %7\n\t"
-        "s_nop 1"
-        : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]));
-  }
-#pragma unroll
-  for (int i = 0; i < N; ++i) x[i] += y[i];
-}
-template <int N>
-__device__ __forceinline__ void swap16_stage(float* x, float* y) {
-  static_assert(N == 4 || N == 2, "pairs per stage");
-  if constexpr (N == 4) {
-    asm volatile(
-        "s_nop 1\n\t"
-        "v_permlane16_swap_b32 %0, %4\n\tv_permlane16_swap_b32 %1, %5\n\t"
-        "v_permlane16_swap_b32 %2, %6\n\tv_permlane16_swap_b32 %3, %7\n\t"
-        "s_nop 1"
-        : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]));
-  } else {
-    asm volatile(
-        "s_nop 1\n\t"
-        "v_permlane16_swap_b32 %0, %2\n\tv_permlane16_swap_b32 %1, %3\n\t"
-        "s_nop 1"
-        : "+v"(x[0]), "+v"(x[1]), "+v"(y[0]), "+v"(y[1]));
-  }
-#pragma unroll
-  for (int i = 0; i < N; ++i) x[i] += y[i];
-}
 
 template <typename T, int kItems>
 __global__ __launch_bounds__(kScanThreads, 2) void scan_bwd_kernel(ScanArgs p) {
@@ -326,6 +274,12 @@ static int launch_bwd(const ScanArgs& a, hipStream_t s) {
   return static_cast<int>(hipGetLastError());
 }
 
+struct BwdSeqArgs;
+bool scan_bwd_seq_ok(int batch, int dim, int seqlen, int dstate, int softplus, int vec, long long z_bs, long long dz_bs,
+                     bool has_z, int bc_mode, long long bc_ns, long long bc_ts);
+int scan_bwd_seq_dispatch(const ScanArgs& a, int io_dtype, int bc_mode, hipStream_t s);
+int scan_fwd_seq_bc_mode(const void* B, const void* C, int io_dtype, long long bc_bs, long long bc_ns, long long bc_ts);
+
 }  // namespace simamba
 
 using namespace simamba;
@@ -339,8 +293,10 @@ extern "C" int simamba_selective_scan_bwd(const void* u, const void* delta, cons
                                           void* dz, float* ddelta_bias, int batch, int dim, int seqlen,
                                           int dstate, int io_dtype, int delta_softplus, long long z_bstride,
                                           long long dz_bstride, long long bc_bstride, long long bc_nstride,
-                                          long long bc_tstride, void* stream) {
+                                          long long bc_tstride, int ckpt_step, void* stream) {
   if (batch < 0 || dim <= 0 || seqlen < 0 || batch > 65535) return SIMAMBA_E_SHAPE;
+  if (ckpt_step == 0) ckpt_step = SIMAMBA_SCAN_CKPT_ROW;
+  if (ckpt_step != SIMAMBA_SCAN_CKPT_ROW && ckpt_step != SIMAMBA_SCAN_CKPT_SEQ) return SIMAMBA_E_VARIANT;
   if (dstate < 1 || dstate > kMaxState) return SIMAMBA_E_DSTATE;
   if (io_dtype != SIMAMBA_F32 && io_dtype != SIMAMBA_BF16) return SIMAMBA_E_DTYPE;
   if (!A || !dA) return SIMAMBA_E_NULLPTR;
@@ -349,7 +305,7 @@ extern "C" int simamba_selective_scan_bwd(const void* u, const void* delta, cons
     if ((z != nullptr) != (dz != nullptr)) return SIMAMBA_E_NULLPTR;
   }
   const int nchunks = simamba_scan_num_chunks(seqlen);
-  if (nchunks > 1 && !x_ckpt) return SIMAMBA_E_NULLPTR;
+  if (ckpt_step == SIMAMBA_SCAN_CKPT_SEQ ? (seqlen > 16 && !x_ckpt) : (nchunks > 1 && !x_ckpt)) return SIMAMBA_E_NULLPTR;
   hipStream_t s = static_cast<hipStream_t>(stream);
   hipError_t e;
   // The five accumulators are zeroed here (the kernel adds into them).  Never a byte outside the five spans:
@@ -395,6 +351,14 @@ extern "C" int simamba_selective_scan_bwd(const void* u, const void* delta, cons
   a.vec = ((seqlen * esz) % 16 == 0) && aligned16b(u) && aligned16b(delta) && aligned16b(dout) &&
           aligned16b(du) && aligned16b(ddelta) &&
           (!z || (aligned16b(z) && aligned16b(dz) && (a.z_bs * esz) % 16 == 0 && (a.dz_bs * esz) % 16 == 0));
+  if (ckpt_step == SIMAMBA_SCAN_CKPT_SEQ) {
+    const int bc_mode = scan_fwd_seq_bc_mode(B, C, io_dtype, a.bc_bs, a.bc_ns, a.bc_ts);
+    if (!scan_bwd_seq_ok(batch, dim, seqlen, dstate, delta_softplus, a.vec, a.z_bs, a.dz_bs, z != nullptr, bc_mode,
+                         a.bc_ns, a.bc_ts) ||
+        (reinterpret_cast<uintptr_t>(A) & 15u) != 0 || (x_ckpt && (reinterpret_cast<uintptr_t>(x_ckpt) & 15u) != 0))
+      return SIMAMBA_E_VARIANT;
+    return scan_bwd_seq_dispatch(a, io_dtype, bc_mode, s);
+  }
   // channels per workgroup (16 * passes): the more, the fewer dB/dC atomics reach HBM (measured at
   // (64,768,1024,16): 134 MB of flush traffic at passes = 3, 18 % on top of the 604 MB of gradient stores);
   // but keep >= 2 workgroups per CU, the number resident at this kernel's register footprint.

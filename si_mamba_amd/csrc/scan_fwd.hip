@@ -159,7 +159,8 @@ static int launch_fwd(const ScanArgs& a, hipStream_t s) {
 }
 
 int scan_fwd_seq_dispatch(const void* u, const void* delta, const float* A, const void* B, const void* C, const float* D,
-                          const void* z, const float* delta_bias, void* out, float* x_ckpt, float* last_state,
+                          const void* z, const float* delta_bias, void* out, float* x_ckpt, int ckpt_step,
+                          float* last_state,
                           int batch, int dim, int seqlen, int io_dtype, long long z_bs,
                           long long bc_bs, long long bc_ns, long long bc_ts, int nchunks128, int lpc, hipStream_t s);
 int scan_fwd_seq_bc_mode(const void* B, const void* C, int io_dtype, long long bc_bs, long long bc_ns, long long bc_ts);
@@ -196,6 +197,27 @@ extern "C" int simamba_scan_fwd_auto_variant(int batch, int dim) {
   return auto_variant(static_cast<long long>(batch) * dim, batch, dim);
 }
 
+// Which checkpoints a forward / backward pair should use when the caller leaves it to the library.  The sequential
+// backward (scan_bwd_seq.hip, 16-step checkpoints written by a lanes-per-channel forward) is taken from the row
+// count on at which that forward is: below it neither has enough waves for the chip.
+extern "C" int simamba_scan_ckpt_step(int batch, int dim, int seqlen, int dstate, int io_dtype) {
+  if (batch <= 0 || dim <= 0 || seqlen <= 0) return SIMAMBA_SCAN_CKPT_ROW;
+  const long long rows = static_cast<long long>(batch) * dim;
+  const int pack = io_dtype == SIMAMBA_F32 ? 4 : 8;
+  if (dstate == kMaxState && dim % 64 == 0 && seqlen % pack == 0 && rows * seqlen < (1ll << 30) &&
+      auto_variant(rows, batch, dim) != SIMAMBA_SCAN_ROWSCAN)
+    return SIMAMBA_SCAN_CKPT_SEQ;
+  return SIMAMBA_SCAN_CKPT_ROW;
+}
+
+extern "C" long long simamba_scan_ckpt_floats(int batch, int dim, int seqlen, int dstate, int ckpt_step) {
+  if (batch <= 0 || dim <= 0 || seqlen <= 0 || dstate <= 0) return 0;
+  if (ckpt_step == SIMAMBA_SCAN_CKPT_SEQ)
+    return seqlen <= 16 ? 0 : static_cast<long long>(batch) * ((seqlen + 15) / 16) * dim * kMaxState;
+  const int nc = simamba_scan_num_chunks(seqlen);
+  return nc <= 1 ? 0 : static_cast<long long>(batch) * dim * nc * dstate;
+}
+
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 extern "C" int simamba_selective_scan_fwd(const void* u, const void* delta, const float* A, const void* B,
@@ -204,8 +226,10 @@ extern "C" int simamba_selective_scan_fwd(const void* u, const void* delta, cons
                                           float* last_state, int batch, int dim, int seqlen, int dstate,
                                           int io_dtype, int delta_softplus, long long z_bstride,
                                           long long bc_bstride, long long bc_nstride, long long bc_tstride,
-                                          int variant, void* stream) {
+                                          int ckpt_step, int variant, void* stream) {
   if (batch < 0 || dim <= 0 || seqlen < 0 || batch > 65535) return SIMAMBA_E_SHAPE;
+  if (ckpt_step == 0) ckpt_step = SIMAMBA_SCAN_CKPT_ROW;
+  if (ckpt_step != SIMAMBA_SCAN_CKPT_ROW && ckpt_step != SIMAMBA_SCAN_CKPT_SEQ) return SIMAMBA_E_VARIANT;
   if (dstate < 1 || dstate > kMaxState) return SIMAMBA_E_DSTATE;
   if (io_dtype != SIMAMBA_F32 && io_dtype != SIMAMBA_BF16) return SIMAMBA_E_DTYPE;
   if (batch == 0 || seqlen == 0) return SIMAMBA_OK;   // nothing to do (empty tensors carry NULL data)
@@ -237,12 +261,19 @@ extern "C" int simamba_selective_scan_fwd(const void* u, const void* delta, cons
                       (reinterpret_cast<uintptr_t>(A) & 15u) == 0 && a.bc_ns >= 0 && a.bc_ts >= 0 &&
                       (kMaxState - 1) * a.bc_ns + (seqlen - 1) * a.bc_ts < (1ll << 30);
   int v = variant == SIMAMBA_SCAN_AUTO ? auto_variant(rows, batch, dim) : variant;
+  // 16-step checkpoints are written by the lanes-per-channel kernels only (four lanes per channel where two would
+  // leave the chip short of waves)
+  const bool want_seq_ckpt = x_ckpt && ckpt_step == SIMAMBA_SCAN_CKPT_SEQ;
+  if (want_seq_ckpt && v == SIMAMBA_SCAN_ROWSCAN) {
+    if (variant != SIMAMBA_SCAN_AUTO) return SIMAMBA_E_VARIANT;
+    v = SIMAMBA_SCAN_LPC4;
+  }
   if (v != SIMAMBA_SCAN_ROWSCAN && !seq_ok) {
-    if (variant != SIMAMBA_SCAN_AUTO) return SIMAMBA_E_VARIANT;     // an explicit request the shape cannot take
+    if (variant != SIMAMBA_SCAN_AUTO || want_seq_ckpt) return SIMAMBA_E_VARIANT;   // a request the shape cannot take
     v = SIMAMBA_SCAN_ROWSCAN;
   }
   if (v != SIMAMBA_SCAN_ROWSCAN)
-    return scan_fwd_seq_dispatch(u, delta, A, B, C, D, z, delta_bias, out, x_ckpt, last_state, batch, dim, seqlen,
+    return scan_fwd_seq_dispatch(u, delta, A, B, C, D, z, delta_bias, out, x_ckpt, ckpt_step, last_state, batch, dim, seqlen,
                                  io_dtype, a.z_bs, a.bc_bs, a.bc_ns, a.bc_ts, a.nchunks,
                                  v == SIMAMBA_SCAN_MIX ? 6 : v == SIMAMBA_SCAN_LPC2 ? 2 : 4, s);
   // channels per workgroup: amortise the (B_t,C_t) staging, but keep >= ~3 workgroups per CU

@@ -49,6 +49,8 @@ struct SeqArgs {
   const void* B;
   const void* C;
   float* x_ckpt;
+  float* ckpt16;                           // state at every 16-step boundary, (batch, nck16, dim, 16): what the
+  int nck16;                               // sequential backward (scan_bwd_seq.hip) starts its segments from
   float* last_state;
   int batch, dim, seqlen, nchunks128;
   int bc_mode;                             // 1 time-major packs of B / C, 2 token-major packs
@@ -311,6 +313,16 @@ __device__ __forceinline__ void seq_body(const SeqArgs& p, const int b, const in
       // all kLPC lanes of a channel hold the same sums and store them to the same place (no EXEC games
       // next to DPP code)
       *reinterpret_cast<float4*>(tU + o) = make_float4(yy[0], yy[1], yy[2], yy[3]);
+      // the state after steps 15 and 31 of the chunk, for a backward that recomputes 16-step segments
+      if (p.ckpt16 && (g & 3) == 3 && own_valid) {
+        const int kb = (t0 >> 4) + (g >> 2);
+        if (kb < p.nck16) {
+          float4* dst = reinterpret_cast<float4*>(
+              p.ckpt16 + ((static_cast<size_t>(b) * p.nck16 + kb) * D + d_own) * kMaxState + n0);
+#pragma unroll
+          for (int k = 0; k < NS / 4; ++k) dst[k] = make_float4(h[4 * k], h[4 * k + 1], h[4 * k + 2], h[4 * k + 3]);
+        }
+      }
     }
     // B | C of the next chunk: requested only now so that their registers are free during the recurrence; the
     // latency hides under phase C and phase A
@@ -437,13 +449,16 @@ int scan_fwd_seq_mix_c4(int batch, int dim) {
 // Entry used by simamba_selective_scan_fwd (scan_fwd.hip) when the shape qualifies (16 states, softplus on,
 // pack-aligned rows and B / C, 32-bit byte offsets); lpc = 2 or 4, or 6 = the mixed launch (scan_fwd_seq_mix_c4 != 0).
 int scan_fwd_seq_dispatch(const void* u, const void* delta, const float* A, const void* B, const void* C, const float* D,
-                          const void* z, const float* delta_bias, void* out, float* x_ckpt, float* last_state,
+                          const void* z, const float* delta_bias, void* out, float* x_ckpt, int ckpt_step,
+                          float* last_state,
                           int batch, int dim, int seqlen, int io_dtype, long long z_bs,
                           long long bc_bs, long long bc_ns, long long bc_ts, int nchunks128, int lpc, hipStream_t s) {
   SeqArgs a{};
   a.u = u; a.delta = delta; a.z = z; a.out = out; a.A = A; a.D = D; a.delta_bias = delta_bias;
   a.B = B; a.C = C;
-  a.x_ckpt = x_ckpt; a.last_state = last_state;
+  if (ckpt_step == SIMAMBA_SCAN_CKPT_SEQ) { a.ckpt16 = x_ckpt; a.nck16 = (seqlen + 15) / 16; }
+  else a.x_ckpt = x_ckpt;
+  a.last_state = last_state;
   a.batch = batch; a.dim = dim; a.seqlen = seqlen; a.nchunks128 = nchunks128;
   a.z_bs = z_bs;
   a.bc_bs = bc_bs; a.bc_ns = bc_ns; a.bc_ts = bc_ts;

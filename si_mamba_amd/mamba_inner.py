@@ -161,23 +161,23 @@ class MambaInnerFn(torch.autograd.Function):
                 delta = _wx(dtw_c, x_dbl[:, :, :R].transpose(1, 2))                    # (B, D, L)
         Bv, Cv = x_dbl[:, :, R:R + N], x_dbl[:, :, R + N:]                            # (B, L, N) views
 
-        nchunks = lib.simamba_scan_num_chunks(L)
         need_grad = any(ctx.needs_input_grad)
-        x_ckpt = (torch.empty(Bsz, Dm, nchunks, N, device=dev, dtype=torch.float32)
-                  if (need_grad and nchunks > 1) else None)
+        aligned = xz.data_ptr() % 16 == 0 and (xbs * xz.element_size()) % 16 == 0 and x_dbl.data_ptr() % 16 == 0
+        ckpt_step, x_ckpt = _lib.scan_plan(Bsz, Dm, L, N, io, aligned, dev, need_grad)
         y = torch.empty(Bsz, Dm, L, device=dev, dtype=io)
         with torch.cuda.device(dev), _lib.timed("scan_fwd", dev):
             rc = lib.simamba_selective_scan_fwd(
                 x_conv.data_ptr(), delta.data_ptr(), Af.data_ptr(), Bv.data_ptr(), Cv.data_ptr(), _lib.ptr(Df),
                 z.data_ptr(), _lib.ptr(bf), y.data_ptr(), _lib.ptr(x_ckpt), None,
                 Bsz, Dm, L, N, code, 1, xbs, x_dbl.stride(0), 1, x_dbl.stride(1),
-                _lib.current_scan_variant(), stream)
+                ckpt_step, _lib.current_scan_variant(), stream)
         _lib.check(rc, "simamba_selective_scan_fwd")
 
         out = _xw(y.transpose(1, 2), ow_c.t())                                         # (B, L, d)
         if out_proj_b is not None:
             out = out + _w(out_proj_b, io)
         ctx.dims = (R, N, W)
+        ctx.ckpt_step = ckpt_step
         ctx.has_out_bias = out_proj_b is not None
         ctx.param_dtypes = (conv_w.dtype, None if conv_b is None else conv_b.dtype, x_proj_w.dtype,
                             dt_proj_w.dtype, out_proj_w.dtype, A.dtype,
@@ -225,7 +225,7 @@ class MambaInnerFn(torch.autograd.Function):
                 z.data_ptr(), _lib.ptr(bf), dy.data_ptr(), _lib.ptr(x_ckpt),
                 du.data_ptr(), ddelta.data_ptr(), dA.data_ptr(), dB.data_ptr(), dC.data_ptr(), _lib.ptr(dD),
                 dz.data_ptr(), _lib.ptr(dbias), Bsz, Dm, L, N, code, 1,
-                xbs, dxz.stride(0), x_dbl.stride(0), 1, x_dbl.stride(1), stream)
+                xbs, dxz.stride(0), x_dbl.stride(0), 1, x_dbl.stride(1), ctx.ckpt_step, stream)
         _lib.check(rc, "simamba_selective_scan_bwd")
 
         # dt_proj / x_proj

@@ -56,10 +56,9 @@ class SelectiveScanFn(torch.autograd.Function):
             zc = zc.contiguous()
         bc = None if delta_bias is None else delta_bias.float().contiguous()
         out = torch.empty_like(uc)
-        nchunks = lib.simamba_scan_num_chunks(L)
         needs_grad = any(t is not None and t.requires_grad for t in (u, delta, A, B, C, D, z, delta_bias))
-        x_ckpt = (torch.empty(batch, dim, nchunks, N, device=u.device, dtype=torch.float32)
-                  if (needs_grad and nchunks > 1) else None)
+        aligned = all(t is None or t.data_ptr() % 16 == 0 for t in (uc, dc, Bc, Cc, zc))
+        ckpt_step, x_ckpt = _lib.scan_plan(batch, dim, L, N, io, aligned and bool(delta_softplus), u.device, needs_grad)
         last = (torch.empty(batch, dim, N, device=u.device, dtype=torch.float32)
                 if return_last_state else None)
         with torch.cuda.device(u.device), _lib.timed("scan_fwd", u.device):
@@ -68,9 +67,10 @@ class SelectiveScanFn(torch.autograd.Function):
                 _lib.ptr(zc), _lib.ptr(bc), _lib.ptr(out), _lib.ptr(x_ckpt), _lib.ptr(last),
                 batch, dim, L, N, code, int(bool(delta_softplus)),
                 0 if zc is None else zc.stride(0), Bc.stride(0), Bc.stride(1), Bc.stride(2),
-                _lib.current_scan_variant(), _lib.stream_ptr(u.device))
+                ckpt_step, _lib.current_scan_variant(), _lib.stream_ptr(u.device))
         _lib.check(rc, "simamba_selective_scan_fwd")
         ctx.delta_softplus = bool(delta_softplus)
+        ctx.ckpt_step = ckpt_step
         ctx.has = (D is not None, z is not None, delta_bias is not None)
         ctx.in_dtypes = (delta.dtype, B.dtype, C.dtype,
                          None if D is None else D.dtype,
@@ -102,7 +102,7 @@ class SelectiveScanFn(torch.autograd.Function):
                 _lib.ptr(du), _lib.ptr(ddelta), _lib.ptr(dA), _lib.ptr(dB), _lib.ptr(dC), _lib.ptr(dD),
                 _lib.ptr(dz), _lib.ptr(dbias), batch, dim, L, N, _lib.dtype_code(io),
                 int(ctx.delta_softplus), 0 if zc is None else zc.stride(0), 0,
-                Bc.stride(0), Bc.stride(1), Bc.stride(2), _lib.stream_ptr(uc.device))
+                Bc.stride(0), Bc.stride(1), Bc.stride(2), ctx.ckpt_step, _lib.stream_ptr(uc.device))
         _lib.check(rc, "simamba_selective_scan_bwd")
         dt_delta, dt_B, dt_C, dt_D, dt_z, dt_bias, dt_A = ctx.in_dtypes
         dB = dB.to(dt_B)

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_version_strerror_and_chunks():
     lib = _lib.load()
-    assert lib.simamba_abi_version() == 8
+    assert lib.simamba_abi_version() == 9
     assert lib.simamba_strerror(0) == b"ok"
     assert b"dstate" in lib.simamba_strerror(-4)
     assert lib.simamba_scan_num_chunks(64) == 1
@@ -40,6 +40,18 @@ def test_version_strerror_and_chunks():
     assert lib.simamba_scan_fwd_auto_variant(32, 768) == 1
     assert lib.simamba_scan_fwd_auto_variant(64, 768) == 2
     assert lib.simamba_scan_fwd_auto_variant(256, 768) == 2
+    # checkpoint plan: the sequential backward (16-step checkpoints) from the row count on at which the forward is a
+    # lanes-per-channel kernel, for shapes it can take; sizes of both layouts
+    assert lib.simamba_scan_ckpt_step(64, 768, 1024, 16, 0) == 16
+    assert lib.simamba_scan_ckpt_step(32, 768, 1024, 16, 0) == 128
+    assert lib.simamba_scan_ckpt_step(64, 768, 1024, 8, 0) == 128
+    assert lib.simamba_scan_ckpt_step(64, 776, 1024, 16, 0) == 128      # dim % 64
+    assert lib.simamba_scan_ckpt_step(64, 768, 1022, 16, 0) == 128      # rows not 16-byte aligned
+    assert lib.simamba_scan_ckpt_step(64, 768, 1020, 16, 1) == 128      # bf16: 8-element packs
+    assert lib.simamba_scan_ckpt_floats(64, 768, 1024, 16, 16) == 64 * 64 * 768 * 16
+    assert lib.simamba_scan_ckpt_floats(64, 768, 1024, 16, 128) == 64 * 768 * 8 * 16
+    assert lib.simamba_scan_ckpt_floats(64, 768, 16, 16, 16) == 0
+    assert lib.simamba_scan_ckpt_floats(64, 768, 128, 16, 128) == 0
     assert lib.simamba_spectral_workspace_bytes(4, 128) == 256 + 4 * 128 * 128 * 4
     assert b"variant" in lib.simamba_strerror(-9)
 
@@ -48,13 +60,16 @@ def test_argument_validation_precedes_any_launch():
     lib = _lib.load()
     n = None
     one = ctypes.c_void_p(16)   # never dereferenced: every call below fails validation first
-    assert lib.simamba_selective_scan_fwd(n, n, n, n, n, n, n, n, n, n, n, 1, 1, 1, 16, 0, 1, 0, 0, 0, 0, 0, n) == -1
-    assert lib.simamba_selective_scan_fwd(one, one, one, one, one, n, n, n, one, n, n, 1, 8, 8, 17, 0, 1, 0, 0, 0, 0, 0, n) == -4
-    assert lib.simamba_selective_scan_fwd(one, one, one, one, one, n, n, n, one, n, n, 1, 8, 8, 16, 7, 1, 0, 0, 0, 0, 0, n) == -3
-    assert lib.simamba_selective_scan_fwd(one, one, one, one, one, n, n, n, one, n, n, 0, 8, 8, 16, 0, 1, 0, 0, 0, 0, 0, n) == 0
+    assert lib.simamba_selective_scan_fwd(n, n, n, n, n, n, n, n, n, n, n, 1, 1, 1, 16, 0, 1, 0, 0, 0, 0, 0, 0, n) == -1
+    assert lib.simamba_selective_scan_fwd(one, one, one, one, one, n, n, n, one, n, n, 1, 8, 8, 17, 0, 1, 0, 0, 0, 0, 0, 0, n) == -4
+    assert lib.simamba_selective_scan_fwd(one, one, one, one, one, n, n, n, one, n, n, 1, 8, 8, 16, 7, 1, 0, 0, 0, 0, 0, 0, n) == -3
+    assert lib.simamba_selective_scan_fwd(one, one, one, one, one, n, n, n, one, n, n, 0, 8, 8, 16, 0, 1, 0, 0, 0, 0, 0, 0, n) == 0
     # an unknown kernel variant, and an explicit lanes-per-channel request the shape cannot take (dstate != 16)
-    assert lib.simamba_selective_scan_fwd(one, one, one, one, one, n, n, n, one, n, n, 1, 8, 8, 16, 0, 1, 0, 0, 0, 0, 3, n) == -9
-    assert lib.simamba_selective_scan_fwd(one, one, one, one, one, n, n, n, one, n, n, 1, 8, 8, 8, 0, 1, 0, 0, 0, 0, 2, n) == -9
+    assert lib.simamba_selective_scan_fwd(one, one, one, one, one, n, n, n, one, n, n, 1, 8, 8, 16, 0, 1, 0, 0, 0, 0, 0, 3, n) == -9
+    assert lib.simamba_selective_scan_fwd(one, one, one, one, one, n, n, n, one, n, n, 1, 8, 8, 8, 0, 1, 0, 0, 0, 0, 0, 2, n) == -9
+    # a checkpoint layout that does not exist; 16-step checkpoints from the row-scan kernel
+    assert lib.simamba_selective_scan_fwd(one, one, one, one, one, n, n, n, one, one, n, 1, 64, 64, 16, 0, 1, 0, 0, 0, 0, 32, 0, n) == -9
+    assert lib.simamba_selective_scan_fwd(one, one, one, one, one, n, n, n, one, one, n, 1, 64, 64, 16, 0, 1, 0, 0, 0, 0, 16, 1, n) == -9
     assert lib.simamba_causal_conv1d_fwd(one, one, n, one, 1, 8, 8, 5, 1, 0, 0, n) == -5
     assert lib.simamba_laplacian_topk(one, n, n, n, n, n, 1, 129, 4, 0, n) == -7
     assert lib.simamba_knn_graph(one, one, n, 0, 1, 16, 3, 16, 1.0, 0, n) == -7

@@ -403,7 +403,7 @@ def test_scan_backward_writes_nothing_outside_its_accumulators(device):
     rc = lib.simamba_selective_scan_fwd(_lib.ptr(t["u"]), _lib.ptr(t["delta"]), _lib.ptr(t["A"]), _lib.ptr(t["B"]),
                                         _lib.ptr(t["C"]), _lib.ptr(t["D"]), _lib.ptr(t["z"]),
                                         _lib.ptr(t["delta_bias"]), _lib.ptr(out), None, None, b, d, L, N, 0, 1,
-                                        0, 0, 0, 0, 0, st)
+                                        0, 0, 0, 0, 0, 0, st)
     assert rc == 0
 
     def bwd(acc):
@@ -412,7 +412,7 @@ def test_scan_backward_writes_nothing_outside_its_accumulators(device):
             _lib.ptr(t["u"]), _lib.ptr(t["delta"]), _lib.ptr(t["A"]), _lib.ptr(t["B"]), _lib.ptr(t["C"]),
             _lib.ptr(t["D"]), _lib.ptr(t["z"]), _lib.ptr(t["delta_bias"]), _lib.ptr(t["dout"]), None,
             _lib.ptr(du), _lib.ptr(dd), *[_lib.ptr(a) for a in acc[:4]], _lib.ptr(dz), _lib.ptr(acc[4]),
-            b, d, L, N, 0, 1, 0, 0, 0, 0, 0, st)
+            b, d, L, N, 0, 1, 0, 0, 0, 0, 0, 0, st)
         assert rc == 0
         return du, dd, dz
 

@@ -15,6 +15,11 @@ from oracle.gen_golden import SPECTRAL_COMBOS, unit_ball_centers
 
 pytestmark = pytest.mark.gpu
 
+# spectral_*: outputs of this repo's oracle; ref_spectral_*: outputs of the REFERENCE's own function bodies on the same
+# centres (oracle/pin_from_reference.py; same keys).  Every parity test below runs against both families.
+FIXTURES = ["spectral_g64", "spectral_g128", "spectral_g128_surface",
+            "ref_spectral_g64", "ref_spectral_g128", "ref_spectral_g128_surface"]
+
 
 def align_sign(got, want):
     """flip each got[:, :, i] to the sign that best matches want[:, :, i]"""
@@ -45,7 +50,7 @@ def assert_order_matches_oracle(order, sgn, wvecs, worder, err, tag):
     return (order == want).sum().item(), order.numel()
 
 
-@pytest.mark.parametrize("name", ["spectral_g64", "spectral_g128", "spectral_g128_surface"])
+@pytest.mark.parametrize("name", FIXTURES)
 def test_graph_adjacency_bit_exact(name, device):
     from si_mamba_amd import spectral
     g = load_golden(name)
@@ -61,7 +66,7 @@ def test_graph_adjacency_bit_exact(name, device):
     np.testing.assert_allclose(adj0, g["sigma_mean.adj"], rtol=2e-6, atol=0)
 
 
-@pytest.mark.parametrize("name", ["spectral_g64", "spectral_g128", "spectral_g128_surface"])
+@pytest.mark.parametrize("name", FIXTURES)
 def test_eigenpairs_and_orders(name, device):
     from si_mamba_amd import spectral
     g = load_golden(name)
@@ -179,7 +184,7 @@ def test_hlt_assembly_matches_reference_restated(device):
     assert gt.shape == (B, 2 * G, 32) and (gt[:, 10 * 16:] == 0).all()      # the reference's unwritten tail
 
 
-@pytest.mark.parametrize("name", ["spectral_g64", "spectral_g128", "spectral_g128_surface"])
+@pytest.mark.parametrize("name", FIXTURES)
 def test_topk_only_path_matches_full_solver_and_oracle(name, device):
     """spectral_order / laplacian_topk without the full-spectrum outputs runs the tridiagonal kernel; it must
     agree with the Jacobi kernel (full path) and meet the same parity bar against the oracle."""
@@ -219,7 +224,7 @@ def test_topk_only_path_matches_full_solver_and_oracle(name, device):
     np.testing.assert_allclose(v.cpu().numpy(), g["hardest.largest.vals"], atol=2e-5)
 
 
-@pytest.mark.parametrize("name", ["spectral_g64", "spectral_g128", "spectral_g128_surface"])
+@pytest.mark.parametrize("name", FIXTURES)
 def test_spectral_order_from_centres_matches_golden_order(name, device):
     """The fused call every model forward makes (centres -> graph -> tridiagonal top-k -> argsort, reference :872 +
     :884 + :889-890) against the oracle's golden orders, for every flag set the reference's configs use."""

@@ -16,7 +16,8 @@ B, D, L, N = 64, 768, 1024, 16
 t = {k: v.to(dev) for k, v in scan_inputs(B, D, L, N, seed=0).items()}
 lib = _lib.load()
 out = torch.empty_like(t["u"])
-x_ckpt = torch.empty(B, D, lib.simamba_scan_num_chunks(L), N, device=dev)
+CK = int(os.environ.get("SIMAMBA_CKPT", "0")) or lib.simamba_scan_ckpt_step(B, D, L, N, 0)   # 16: sequential backward
+x_ckpt = torch.empty(lib.simamba_scan_ckpt_floats(B, D, L, N, CK), device=dev)
 du, dd, dz = (torch.empty_like(t["u"]) for _ in range(3))
 acc = _lib.scan_bwd_accumulators(B, D, L, N, True, True, dev)
 
@@ -24,7 +25,7 @@ acc = _lib.scan_bwd_accumulators(B, D, L, N, True, True, dev)
 def scan_fwd(st):
     assert lib.simamba_selective_scan_fwd(t["u"].data_ptr(), t["delta"].data_ptr(), t["A"].data_ptr(), t["B"].data_ptr(),
                                           t["C"].data_ptr(), t["D"].data_ptr(), t["z"].data_ptr(), t["delta_bias"].data_ptr(),
-                                          out.data_ptr(), x_ckpt.data_ptr(), None, B, D, L, N, 0, 1, 0, 0, 0, 0, 0, st) == 0
+                                          out.data_ptr(), x_ckpt.data_ptr(), None, B, D, L, N, 0, 1, 0, 0, 0, 0, CK, 0, st) == 0
 
 
 def scan_bwd(st):
@@ -32,7 +33,7 @@ def scan_bwd(st):
                                           t["C"].data_ptr(), t["D"].data_ptr(), t["z"].data_ptr(), t["delta_bias"].data_ptr(),
                                           t["dout"].data_ptr(), x_ckpt.data_ptr(), du.data_ptr(), dd.data_ptr(),
                                           acc[0].data_ptr(), acc[1].data_ptr(), acc[2].data_ptr(), acc[3].data_ptr(),
-                                          dz.data_ptr(), acc[4].data_ptr(), B, D, L, N, 0, 1, 0, 0, 0, 0, 0, st) == 0
+                                          dz.data_ptr(), acc[4].data_ptr(), B, D, L, N, 0, 1, 0, 0, 0, 0, 0, CK, st) == 0
 
 
 dxz = torch.randn(B, 2 * D, L, device=dev)
