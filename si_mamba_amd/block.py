@@ -60,8 +60,10 @@ class Block(nn.Module):
         self.norm = norm_cls(dim)
         self.drop_path = DropPath(drop_path) if drop_path > 0. else nn.Identity()
 
-    def forward(self, hidden_states: Tensor, residual: Optional[Tensor] = None, inference_params=None):
-        """hidden_states = Mixer(LN(residual)); returns (hidden_states, residual).
+    def forward(self, hidden_states: Tensor, residual: Optional[Tensor] = None, inference_params=None, A=None):
+        """hidden_states = Mixer(LN(residual)); returns (hidden_states, residual).  ``A`` (optional, specific to this
+        implementation): the mixer's -exp(A_log) when the caller has already formed it (MixerModel does, for all
+        layers in one launch); handed on as an argument, never parked on the module.
 
         Add (+ DropPath) + LayerNorm run as one HIP pass each way (add_norm.py) for LayerNorm blocks on the
         GPU; the composed torch form below is the reference's own and serves any other norm / device."""
@@ -74,7 +76,10 @@ class Block(nn.Module):
             hidden_states = self.norm(residual.to(dtype=self.norm.weight.dtype))
             if self.residual_in_fp32:
                 residual = residual.to(torch.float32)
-        hidden_states = self.mixer(hidden_states, inference_params=inference_params)
+        if A is not None:
+            hidden_states = self.mixer(hidden_states, inference_params=inference_params, A=A)
+        else:
+            hidden_states = self.mixer(hidden_states, inference_params=inference_params)
         return hidden_states, residual
 
     def allocate_inference_cache(self, batch_size, max_seqlen, dtype=None, **kwargs):
@@ -135,7 +140,7 @@ class MixerModel(nn.Module):
         return {i: layer.allocate_inference_cache(batch_size, max_seqlen, dtype=dtype, **kwargs)
                 for i, layer in enumerate(self.layers)}
 
-    def _first_block_on_distinct_tokens(self, tokens, pos, token_index):
+    def _first_block_on_distinct_tokens(self, tokens, pos, token_index, A=None):
         """Block 0 when the sequence is ``gather(tokens + pos, token_index)``: Add + LayerNorm + in_proj on the G
         distinct tokens, expanded to the L positions by a copy kernel (seq_expand.py).  -> (hidden, residual) of
         block 0 as the reference's Block.forward returns them, or None when the route does not apply."""
@@ -156,31 +161,34 @@ class MixerModel(nn.Module):
         else:
             normed, res0 = add_layer_norm_fn(tokens + pos, None, layer.norm.weight, layer.norm.bias, layer.norm.eps)
         xz = seq_expand.seq_gather_last(mixer.in_proj_xz(normed), idx32, inv32)          # (B, 2D, L)
-        hidden = mixer.forward_xz(xz)
+        hidden = mixer.forward_xz(xz, A=A)
         residual = torch.gather(res0, 1, token_index.unsqueeze(-1).expand(-1, -1, res0.shape[-1]))
         return hidden, residual
 
     def _precompute_A(self):
         """A = -exp(A_log) of every layer in three launches (stack, exp, neg) instead of two per layer, and one
-        exp / neg backward for all of them; each mixer picks its slice up in forward_xz (mamba_simple.py)."""
+        exp / neg backward for all of them.  -> per-layer list (slices of one tensor) handed to the blocks as an
+        ARGUMENT, or a list of None when the layers are not uniform Mamba mixers on the GPU (each then forms its own)."""
         mixers = [layer.mixer for layer in self.layers]
         if (len(mixers) > 1 and all(type(m) is Mamba for m in mixers) and mixers[0].A_log.is_cuda
                 and all(m.A_log.shape == mixers[0].A_log.shape for m in mixers)):
-            A_all = -torch.exp(torch.stack([m.A_log for m in mixers]).float())
-            for m, A in zip(mixers, A_all.unbind(0)):
-                m._A_pre = A
+            return list((-torch.exp(torch.stack([m.A_log for m in mixers]).float())).unbind(0))
+        return [None] * len(mixers)
 
-    def forward(self, input_ids, pos, inference_params=None, token_index=None):
+    def forward(self, input_ids, pos, inference_params=None, token_index=None, balanced_index=False):
         """Reference signature (models/point_mamba.py:247).  ``token_index`` (B, L) int64, optional and specific to
         this implementation: when given, ``input_ids`` / ``pos`` are the G DISTINCT tokens (B, G, C) and the sequence
-        the reference would be handed is their gather by ``token_index``; the result is the same, the first block's
-        per-token head runs on G tokens instead of L."""
+        the reference would be handed is their gather by ``token_index``; the result is the same.
+        ``balanced_index=True`` is the caller's statement that every token occurs exactly L / G times in every row of
+        ``token_index`` (a concatenation of permutations, which is what the SAST / MAMBA assemblies are): only then
+        does the first block's per-token head run on the G tokens (the adjoint of that expansion sums a fixed number
+        of positions per token); any other index takes the reference's route on the gathered sequence."""
         first = 0
         residual = None
-        self._precompute_A()
+        A_all = self._precompute_A()
         if token_index is not None:
-            done = (self._first_block_on_distinct_tokens(input_ids, pos, token_index)
-                    if inference_params is None else None)
+            done = (self._first_block_on_distinct_tokens(input_ids, pos, token_index, A=A_all[0])
+                    if (balanced_index and inference_params is None) else None)
             if done is not None:
                 hidden_states, residual = done
                 hidden_states = self.drop_out_in_block(hidden_states)
@@ -191,8 +199,9 @@ class MixerModel(nn.Module):
                 pos = torch.gather(pos, 1, ex.expand(-1, -1, pos.shape[-1]))
         if first == 0:
             hidden_states = input_ids + pos
-        for layer in self.layers[first:]:
-            hidden_states, residual = layer(hidden_states, residual, inference_params=inference_params)
+        for i in range(first, len(self.layers)):
+            hidden_states, residual = self.layers[i](hidden_states, residual, inference_params=inference_params,
+                                                     A=A_all[i])
             hidden_states = self.drop_out_in_block(hidden_states)
         if hidden_states.is_cuda and type(self.norm_f) is nn.LayerNorm and hidden_states.dim() == 3:
             # the stack's output norm returns the parameter dtype (fp32) under autocast too, as F.layer_norm does

@@ -151,7 +151,6 @@ __global__ __launch_bounds__(kBsThreads, SIMAMBA_BWDSEQ_OCC) void scan_bwd_seq_k
     A2[0] = a4.x * kLog2e; A2[1] = a4.y * kLog2e; A2[2] = a4.z * kLog2e; A2[3] = a4.w * kLog2e;
   }
   const float Dfull = p.D ? p.D[dch] : 0.f;
-  const float Dl = (pq == 0) ? Dfull : 0.f;                // the skip term enters the state sum of one lane only
   float ga[4] = {0.f, 0.f, 0.f, 0.f};                      // a_{t+1} g_{t+1}: the adjoint state, carried through time
   float dAacc[4] = {0.f, 0.f, 0.f, 0.f};
   float dDacc = 0.f;
@@ -159,14 +158,13 @@ __global__ __launch_bounds__(kBsThreads, SIMAMBA_BWDSEQ_OCC) void scan_bwd_seq_k
   const int trow = ch * kBsTC;
   // element f of a dB | dC row that this lane's finished sum belongs to (see the reduction below)
   const int pf = (r4 >> 1) * 16 + 4 * pq + 2 * (r4 & 1) + (cq >> 1);
+  const float* ckl = p.ckpt + (static_cast<size_t>(b) * p.nck * D + dch) * kMaxState + 4 * pq;   // + block * D * 16
 
   // ---- phase A / C identity: pack pk = lane + 64 j covers row pk / 8, steps 4 (pk % 8) .. + 4 ----------------
-  // Everything derived from the lane id for these phases (byte offsets, tile offsets) is recomputed from an opaque
-  // copy of it after every phase B instead of living in registers through it (phase B needs them all for h).
+  // Phase B needs every register it can get for h (64) and its working set, so NOTHING of phases A / C lives through
+  // it: byte / tile offsets are recomputed from the hardware lane id where they are used, the bias is re-read with the
+  // chunk's operands, and the per-channel sum of ddelta goes out per chunk.
   constexpr unsigned kEsz = sizeof(T);
-  float biasA[2], dbacc[2] = {0.f, 0.f};
-#pragma unroll
-  for (int j = 0; j < 2; ++j) biasA[j] = (p.delta_bias ? p.delta_bias[d0w + (lane >> 3) + 8 * j] : 0.f) * kLog2e;
   // z / dz sit at a wave-uniform distance from u / du (their batch strides may differ)
   const unsigned zdelta = (static_cast<unsigned>(b * p.z_bs) - static_cast<unsigned>(b) * D * L) * kEsz;
   const unsigned dzdelta = (static_cast<unsigned>(b * p.dz_bs) - static_cast<unsigned>(b) * D * L) * kEsz;
@@ -177,18 +175,13 @@ __global__ __launch_bounds__(kBsThreads, SIMAMBA_BWDSEQ_OCC) void scan_bwd_seq_k
   T* __restrict__ dug = static_cast<T*>(p.du);
   T* __restrict__ ddg = static_cast<T*>(p.ddelta);
   T* __restrict__ dzg = static_cast<T*>(p.dz);
-  int lane_v = lane, tid_v = tid;
-  unsigned rowoff[2];
-  int toff[2];
-  auto lane_offsets = [&]() {
-    asm volatile("" : "+v"(lane_v), "+v"(tid_v));
-    const int qv = lane_v & 7;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int row = (lane_v >> 3) + 8 * j;
-      rowoff[j] = ((static_cast<unsigned>(b) * D + d0w + row) * L + 4 * qv) * kEsz;
-      toff[j] = bs_tile_off(row, qv);
-    }
+  auto lane_now = [&]() -> int {                            // 2 VALU; never a loop-carried register
+    int l = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    asm volatile("" : "+v"(l));
+    return l;
+  };
+  auto row_off = [&](int l, int j) -> unsigned {
+    return ((static_cast<unsigned>(b) * D + d0w + (l >> 3) + 8 * j) * L + 4 * (l & 7)) * kEsz;
   };
 
   // ---- B_t | C_t staging: one 4-pack per thread and chunk ------------------------------------------------------
@@ -199,10 +192,10 @@ __global__ __launch_bounds__(kBsThreads, SIMAMBA_BWDSEQ_OCC) void scan_bwd_seq_k
   const T* __restrict__ Bgp = static_cast<const T*>(p.B) + static_cast<long long>(b) * p.bc_bs;
   const T* __restrict__ Cgp = static_cast<const T*>(p.C) + static_cast<long long>(b) * p.bc_bs;
   float bcv[4];
-  auto issue_bc = [&](int t0) {
-    const bool isC = tok ? (tid_v & 4) != 0 : (tid_v >> 7) != 0;
-    const int bc_n = tok ? 4 * (tid_v & 3) : ((tid_v >> 3) & 15);
-    const int bc_tl = tok ? (tid_v >> 3) : 4 * (tid_v & 7);
+  auto issue_bc = [&](int t0, int tv) {
+    const bool isC = tok ? (tv & 4) != 0 : (tv >> 7) != 0;
+    const int bc_n = tok ? 4 * (tv & 3) : ((tv >> 3) & 15);
+    const int bc_tl = tok ? (tv >> 3) : 4 * (tv & 7);
     const int t = (t0 + bc_tl < L) ? t0 + bc_tl : 0;         // beyond the sequence: step 0 (multiplied away)
     const unsigned o = static_cast<unsigned>(bc_n * static_cast<int>(p.bc_ns) + t * static_cast<int>(p.bc_ts)) * kEsz;
     float vb[4], vc[4];                                      // both tensors from uniform bases, one kept
@@ -210,48 +203,47 @@ __global__ __launch_bounds__(kBsThreads, SIMAMBA_BWDSEQ_OCC) void scan_bwd_seq_k
 #pragma unroll
     for (int k = 0; k < 4; ++k) bcv[k] = isC ? vc[k] : vb[k];
   };
-  auto stage_bc = [&]() {
+  auto stage_bc = [&](int tv) {
     if (tok) {
-      *reinterpret_cast<float4*>(tBC + (tid_v >> 3) * 32 + 4 * (tid_v & 7)) = make_float4(bcv[0], bcv[1], bcv[2], bcv[3]);
+      *reinterpret_cast<float4*>(tBC + (tv >> 3) * 32 + 4 * (tv & 7)) = make_float4(bcv[0], bcv[1], bcv[2], bcv[3]);
     } else {
-      float* dst = tBC + 4 * (tid_v & 7) * 32 + (tid_v >> 7) * 16 + ((tid_v >> 3) & 15);
+      float* dst = tBC + 4 * (tv & 7) * 32 + (tv >> 7) * 16 + ((tv >> 3) & 15);
 #pragma unroll
       for (int k = 0; k < 4; ++k) dst[k * 32] = bcv[k];
     }
   };
 
-  // operands of one chunk, requested one chunk ahead: the packs of the load layout and the two checkpoint states
-  float dv[2][4], uv[2][4], gv[2][4], zv[2][4], hsn[2][4];
-  auto issue_loads = [&](int t0) {
-    const int qv = lane_v & 7;
+  // operands of one chunk, requested one chunk ahead: the packs of the load layout, the biases of their rows and the
+  // state entering the chunk's right segment
+  float dv[2][4], uv[2][4], gv[2][4], zv[2][4], hsn[4], biasA[2];
+  auto load_state = [&](int ts) {                            // the forward's checkpoint at step ts - 1; zero at 0
+    float4 h4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ts > 0 && ts < L) h4 = *reinterpret_cast<const float4*>(ckl + static_cast<size_t>(ts / kBsSeg - 1) * D * kMaxState);
+    hsn[0] = h4.x; hsn[1] = h4.y; hsn[2] = h4.z; hsn[3] = h4.w;
+  };
+  auto issue_loads = [&](int t0, int l) {
+    const int qv = l & 7;
     const bool in = t0 + 4 * qv < L;
     const unsigned to = in ? t0 * kEsz : 0u - 4u * qv * kEsz;    // beyond the sequence: the row's first pack
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      bs_load4<T>(dg, rowoff[j] + to, dv[j]);
-      bs_load4<T>(ug, rowoff[j] + to, uv[j]);
-      bs_load4<T>(gg, rowoff[j] + to, gv[j]);
-      if (kHasZ) bs_load4<T>(zg, rowoff[j] + zdelta + to, zv[j]);
+      const unsigned ro = row_off(l, j) + to;
+      bs_load4<T>(dg, ro, dv[j]);
+      bs_load4<T>(ug, ro, uv[j]);
+      bs_load4<T>(gg, ro, gv[j]);
+      if (kHasZ) bs_load4<T>(zg, ro + zdelta, zv[j]);
+      biasA[j] = p.delta_bias ? p.delta_bias[d0w + (l >> 3) + 8 * j] : 0.f;
     }
-    // state entering each 16-step segment: the forward's checkpoint at the step before it (zero at t = 0)
-#pragma unroll
-    for (int sg = 0; sg < 2; ++sg) {
-      const int kb = (t0 >> 4) + sg - 1;                       // block whose end state enters the segment
-      float4 h4 = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (kb >= 0 && t0 + kBsSeg * sg < L)                     // segments beyond the sequence are never run
-        h4 = *reinterpret_cast<const float4*>(
-            p.ckpt + ((static_cast<size_t>(b) * p.nck + kb) * D + dch) * kMaxState + 4 * pq);
-      hsn[sg][0] = h4.x; hsn[sg][1] = h4.y; hsn[sg][2] = h4.z; hsn[sg][3] = h4.w;
-    }
+    load_state(t0 + kBsSeg);
   };
 
   const int nchunks = (L + kBsTC - 1) / kBsTC;
-  lane_offsets();
   {
     const int t0 = (nchunks - 1) * kBsTC;
-    issue_bc(t0);
-    issue_loads(t0);
-    stage_bc();
+    const int l = lane_now();
+    issue_bc(t0, wave * 64 + l);
+    issue_loads(t0, l);
+    stage_bc(wave * 64 + l);
   }
 
   for (int c = nchunks - 1; c >= 0; --c) {
@@ -260,10 +252,11 @@ __global__ __launch_bounds__(kBsThreads, SIMAMBA_BWDSEQ_OCC) void scan_bwd_seq_k
 
     // ---- phase A: per-element transcendentals in the load layout, into the tiles ----------------------------
     {
-      const bool in_seq = t0 + 4 * (lane_v & 7) < L;
+      const int l = lane_now();
+      const bool in_seq = t0 + 4 * (l & 7) < L;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        const float b2 = in_seq ? biasA[j] : -1e30f;           // padded pack: softplus -> 0, the identity step
+        const float b2 = in_seq ? biasA[j] * kLog2e : -1e30f;  // padded pack: softplus -> 0, the identity step
         float dl[4], dyv[4], dzw[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -277,17 +270,13 @@ __global__ __launch_bounds__(kBsThreads, SIMAMBA_BWDSEQ_OCC) void scan_bwd_seq_k
             dyv[i] = go;
           }
         }
-        *reinterpret_cast<float4*>(tD + toff[j]) = make_float4(dl[0], dl[1], dl[2], dl[3]);
-        *reinterpret_cast<float4*>(tU + toff[j]) = make_float4(uv[j][0], uv[j][1], uv[j][2], uv[j][3]);
-        *reinterpret_cast<float4*>(tY + toff[j]) = make_float4(dyv[0], dyv[1], dyv[2], dyv[3]);
-        if (kHasZ) *reinterpret_cast<float4*>(tZ + toff[j]) = make_float4(dzw[0], dzw[1], dzw[2], dzw[3]);
+        const int to_ = bs_tile_off((l >> 3) + 8 * j, l & 7);
+        *reinterpret_cast<float4*>(tD + to_) = make_float4(dl[0], dl[1], dl[2], dl[3]);
+        *reinterpret_cast<float4*>(tU + to_) = make_float4(uv[j][0], uv[j][1], uv[j][2], uv[j][3]);
+        *reinterpret_cast<float4*>(tY + to_) = make_float4(dyv[0], dyv[1], dyv[2], dyv[3]);
+        if (kHasZ) *reinterpret_cast<float4*>(tZ + to_) = make_float4(dzw[0], dzw[1], dzw[2], dzw[3]);
       }
     }
-    float hs2[2][4];
-#pragma unroll
-    for (int sg = 0; sg < 2; ++sg)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) hs2[sg][j] = hsn[sg][j];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
@@ -295,21 +284,19 @@ __global__ __launch_bounds__(kBsThreads, SIMAMBA_BWDSEQ_OCC) void scan_bwd_seq_k
 #pragma unroll 1
     for (int seg = 1; seg >= 0; --seg) {
       const int ts = t0 + kBsSeg * seg;                      // first step of the segment
-      if (ts >= L) continue;                                 // whole segment beyond the sequence (wave-uniform)
-      float hs[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) hs[j] = seg ? hs2[1][j] : hs2[0][j];
+      if (ts >= L) { load_state(t0); continue; }             // whole segment beyond the sequence (wave-uniform)
       const float* bcp = tBC + seg * (kBsSeg * 32) + 4 * pq;
       const int gb = 4 * seg;
 
-      // (1) recompute h_t (kept), y_t -> dz.  LDS reads run one step (B_t | C_t) ahead of their use; the
-      // sched_barriers keep hipcc from sinking them back next to the consumer or hoisting a whole pass of them
+      // (1) recompute h_t (kept), y_t -> dz.  hsn: the state entering the segment (requested a pass or more ago).
       float H[kBsSeg][4];
       {
-        float h[4] = {hs[0], hs[1], hs[2], hs[3]};
+        float h[4] = {hsn[0], hsn[1], hsn[2], hsn[3]};
         float d4[4], u4[4], z4[4];
+#ifndef SIMAMBA_BWDSEQ_NOPREFETCH
         float4 b4n = *reinterpret_cast<const float4*>(bcp);
         float4 c4n = *reinterpret_cast<const float4*>(bcp + 16);
+#endif
 #pragma unroll
         for (int i = 0; i < kBsSeg; ++i) {
           const int o = trow + 4 * ((gb + (i >> 2)) ^ sw);
@@ -323,6 +310,9 @@ __global__ __launch_bounds__(kBsThreads, SIMAMBA_BWDSEQ_OCC) void scan_bwd_seq_k
               z4[0] = zz.x; z4[1] = zz.y; z4[2] = zz.z; z4[3] = zz.w;
             }
           }
+#ifndef SIMAMBA_BWDSEQ_NOPREFETCH
+          // LDS reads run one step (B_t | C_t) ahead of their use; the sched_barriers keep hipcc from sinking them
+          // back next to the consumer or hoisting a whole pass of them
           const float vB[4] = {b4n.x, b4n.y, b4n.z, b4n.w};
           const float vC[4] = {c4n.x, c4n.y, c4n.z, c4n.w};
           {
@@ -331,9 +321,15 @@ __global__ __launch_bounds__(kBsThreads, SIMAMBA_BWDSEQ_OCC) void scan_bwd_seq_k
             c4n = *reinterpret_cast<const float4*>(bcp + in * 32 + 16);
           }
           __builtin_amdgcn_sched_barrier(0);
+#else
+          const float4 b4 = *reinterpret_cast<const float4*>(bcp + i * 32);
+          const float4 c4 = *reinterpret_cast<const float4*>(bcp + i * 32 + 16);
+          const float vB[4] = {b4.x, b4.y, b4.z, b4.w};
+          const float vC[4] = {c4.x, c4.y, c4.z, c4.w};
+#endif
           const float dl = d4[i & 3], uu = u4[i & 3];
           const float xx = dl * uu;
-          float y = Dl * uu;
+          float y = 0.f;
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const float a = fast_exp2(dl * A2[j]);
@@ -343,7 +339,7 @@ __global__ __launch_bounds__(kBsThreads, SIMAMBA_BWDSEQ_OCC) void scan_bwd_seq_k
           }
           if (kHasZ) {
             bs_quad_sum1(y);
-            const float dzv = z4[i & 3] * y;
+            const float dzv = z4[i & 3] * fmaf(Dfull, uu, y);  // dz = dout silu'(z) (C . h + D u)
             if (pq == 0) tZ[o + (i & 3)] = dzv;
           }
           __builtin_amdgcn_sched_barrier(0);
@@ -353,8 +349,10 @@ __global__ __launch_bounds__(kBsThreads, SIMAMBA_BWDSEQ_OCC) void scan_bwd_seq_k
       // (2) the adjoint, right to left
       {
         float d4[4], u4[4], y4[4];
+#ifndef SIMAMBA_BWDSEQ_NOPREFETCH
         float4 b4n = *reinterpret_cast<const float4*>(bcp + (kBsSeg - 1) * 32);
         float4 c4n = *reinterpret_cast<const float4*>(bcp + (kBsSeg - 1) * 32 + 16);
+#endif
 #pragma unroll
         for (int i = kBsSeg - 1; i >= 0; --i) {
           const int o = trow + 4 * ((gb + (i >> 2)) ^ sw);
@@ -366,6 +364,10 @@ __global__ __launch_bounds__(kBsThreads, SIMAMBA_BWDSEQ_OCC) void scan_bwd_seq_k
             u4[0] = uu.x; u4[1] = uu.y; u4[2] = uu.z; u4[3] = uu.w;
             y4[0] = yy.x; y4[1] = yy.y; y4[2] = yy.z; y4[3] = yy.w;
           }
+          // the state entering the next (left) segment is requested once half of the h registers are free again:
+          // the second half of this pass covers its latency, and nothing older is pending in the memory queue
+          if (i == kBsSeg / 2 - 1) load_state(ts - kBsSeg);
+#ifndef SIMAMBA_BWDSEQ_NOPREFETCH
           const float vB[4] = {b4n.x, b4n.y, b4n.z, b4n.w};
           const float vC[4] = {c4n.x, c4n.y, c4n.z, c4n.w};
           {
@@ -374,6 +376,12 @@ __global__ __launch_bounds__(kBsThreads, SIMAMBA_BWDSEQ_OCC) void scan_bwd_seq_k
             c4n = *reinterpret_cast<const float4*>(bcp + in * 32 + 16);
           }
           __builtin_amdgcn_sched_barrier(0);
+#else
+          const float4 b4 = *reinterpret_cast<const float4*>(bcp + i * 32);
+          const float4 c4 = *reinterpret_cast<const float4*>(bcp + i * 32 + 16);
+          const float vB[4] = {b4.x, b4.y, b4.z, b4.w};
+          const float vC[4] = {c4.x, c4.y, c4.z, c4.w};
+#endif
           const float dl = d4[i & 3], uu = u4[i & 3], dy = y4[i & 3];
           const float xx = dl * uu;
           float dxs = 0.f, dda = 0.f;
@@ -383,8 +391,9 @@ __global__ __launch_bounds__(kBsThreads, SIMAMBA_BWDSEQ_OCC) void scan_bwd_seq_k
             const float g = fmaf(vC[j], dy, ga[j]);          // g_t = a_{t+1} g_{t+1} + C_t dy_t
             const float a = fast_exp2(dl * A2[j]);
             ga[j] = g * a;
-            const float hp = (i == 0) ? hs[j] : H[i > 0 ? i - 1 : 0][j];
-            const float qv = ga[j] * hp;                     // g_t a_t h_{t-1}
+            // g_t a_t h_{t-1}; at the segment's first step a_t h_{t-1} = h_t - x_t B_t (the recurrence itself), so the
+            // state that entered the segment need not stay in registers through both passes
+            const float qv = (i > 0) ? ga[j] * H[i > 0 ? i - 1 : 0][j] : g * fmaf(-xx, vB[j], H[0][j]);
             dda = fmaf(A2[j], qv, dda);
             dAacc[j] = fmaf(dl, qv, dAacc[j]);
             dxs = fmaf(g, vB[j], dxs);
@@ -412,61 +421,77 @@ __global__ __launch_bounds__(kBsThreads, SIMAMBA_BWDSEQ_OCC) void scan_bwd_seq_k
         }
       }
     }
-    // the next chunk's operands: requested here, where the h registers are free again and ahead of this chunk's
-    // stores and atomics in the memory queue (a load behind them would wait for them: vmcnt retires in order);
-    // they land during phase C and under the other two waves of this SIMD, which belong to other workgroups
-    lane_offsets();
-    if (c > 0) {
-      issue_loads(t0 - kBsTC);
-      issue_bc(t0 - kBsTC);
-    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __syncthreads();            // every wave's tP is complete and nobody reads this chunk's tBC any more
+    __builtin_amdgcn_wave_barrier();
 
-    // ---- phase C: finish ddelta, store the three gradients in load order; flush dB | dC --------------------
-    if (c > 0) stage_bc();
+    // ---- phase C, own tiles: finish ddelta, store the three gradients in load order --------------------------
     {
-      const bool in_seq = t0 + 4 * (lane_v & 7) < L;
+      const int l = lane_now();
+      const bool in_seq = t0 + 4 * (l & 7) < L;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        const float4 a4 = *reinterpret_cast<const float4*>(tU + toff[j]);
-        const float4 t4 = *reinterpret_cast<const float4*>(tY + toff[j]);
-        const float4 d4 = *reinterpret_cast<const float4*>(tD + toff[j]);
+        const int to_ = bs_tile_off((l >> 3) + 8 * j, l & 7);
+        const float4 a4 = *reinterpret_cast<const float4*>(tU + to_);
+        const float4 t4 = *reinterpret_cast<const float4*>(tY + to_);
+        const float4 d4 = *reinterpret_cast<const float4*>(tD + to_);
         const float duv[4] = {a4.x, a4.y, a4.z, a4.w};
         const float t2[4] = {t4.x, t4.y, t4.z, t4.w};
         const float dl[4] = {d4.x, d4.y, d4.z, d4.w};
-        float dd[4];
+        float dd[4], dsum = 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           // d softplus(x)/dx = sigmoid(x) = 1 - exp(-softplus(x)); padded steps (delta = 0) carry no gradient
           dd[i] = t2[i] * (1.f - fast_exp2(-dl[i] * kLog2e));
-          dbacc[j] += dd[i];
+          dsum += dd[i];
         }
+        const unsigned ro = row_off(l, j) + t0 * kEsz;
         if (in_seq) {
-          bs_store4<T>(dug, rowoff[j] + t0 * kEsz, duv);
-          bs_store4<T>(ddg, rowoff[j] + t0 * kEsz, dd);
+          bs_store4<T>(dug, ro, duv);
+          bs_store4<T>(ddg, ro, dd);
           if (kHasZ) {
-            const float4 z4 = *reinterpret_cast<const float4*>(tZ + toff[j]);
+            const float4 z4 = *reinterpret_cast<const float4*>(tZ + to_);
             const float dzv[4] = {z4.x, z4.y, z4.z, z4.w};
-            bs_store4<T>(dzg, rowoff[j] + dzdelta + t0 * kEsz, dzv);
+            bs_store4<T>(dzg, ro + dzdelta, dzv);
           }
         }
+        // ddelta_bias: this chunk's sum over the row's 8 packs, one atomic per row and chunk
+        if (p.ddelta_bias) {
+          dsum += dpp<DPP_QUAD_XOR1>(0.f, dsum);
+          dsum += dpp<DPP_QUAD_XOR2>(0.f, dsum);
+          dsum += dpp<DPP_ROW_HALF_MIRROR>(0.f, dsum);
+          if ((l & 7) == 0) atomicAdd(&p.ddelta_bias[d0w + (l >> 3) + 8 * j], dsum);
+        }
       }
+      // the next chunk's operands: requested here, where phase B's registers are free, behind this chunk's stores in the
+      // memory queue and AHEAD of the dB | dC atomics (a load issued behind those would wait for them: vmcnt retires
+      // in order); they land during the flush below and under the other two waves of this SIMD
+      // (unconditional: on the last iteration chunk 0 is simply read again -- a load under `if (c > 0)` would keep the
+      // PREVIOUS values of these 44 registers alive through all of phase B, which is exactly where none are free)
+      const int tn = c > 0 ? t0 - kBsTC : 0;
+      issue_loads(tn, l);
+      issue_bc(tn, wave * 64 + l);
     }
+    __syncthreads();            // every wave's tP is complete and nobody reads this chunk's tBC any more
+
+    // ---- phase C, workgroup: stage the next B | C tile, flush dB | dC ------------------------------------------
+    {
+      const int tv = wave * 64 + lane_now();
+      stage_bc(tv);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int e = tid_v + kBsThreads * k;
-      const int f = e >> 5, t = e & 31;
-      float v = 0.f;
+      for (int k = 0; k < 4; ++k) {
+        const int e = tv + kBsThreads * k;
+        const int f = e >> 5, t = e & 31;
+        float v = 0.f;
 #pragma unroll
-      for (int w = 0; w < kBsWaves; ++w) v += smem[w * kBsWaveFloats + 4 * kBsTile + t * kBsPPitch + f];
+        for (int w = 0; w < kBsWaves; ++w) v += smem[w * kBsWaveFloats + 4 * kBsTile + t * kBsPPitch + f];
 #ifdef SIMAMBA_BWDSEQ_NOFLUSH
-      if (t0 + t < L && v == 123.456f) {
+        if (t0 + t < L && v == 123.456f) {
 #else
-      if (t0 + t < L) {
+        if (t0 + t < L) {
 #endif
-        float* dst = ((f >> 4) ? p.dC : p.dB) + (static_cast<size_t>(b) * kMaxState + (f & 15)) * L + t0 + t;
-        atomicAdd(dst, v);
+          float* dst = ((f >> 4) ? p.dC : p.dB) + (static_cast<size_t>(b) * kMaxState + (f & 15)) * L + t0 + t;
+          atomicAdd(dst, v);
+        }
       }
     }
   }
@@ -475,16 +500,6 @@ __global__ __launch_bounds__(kBsThreads, SIMAMBA_BWDSEQ_OCC) void scan_bwd_seq_k
 #pragma unroll
   for (int j = 0; j < 4; ++j) atomicAdd(&p.dA[static_cast<size_t>(dch) * kMaxState + 4 * pq + j], dAacc[j]);
   if (p.dD && pq == 0) atomicAdd(&p.dD[dch], dDacc);
-  if (p.ddelta_bias) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      float v = dbacc[j];
-      v += dpp<DPP_QUAD_XOR1>(0.f, v);
-      v += dpp<DPP_QUAD_XOR2>(0.f, v);
-      v += dpp<DPP_ROW_HALF_MIRROR>(0.f, v);
-      if ((lane & 7) == 0) atomicAdd(&p.ddelta_bias[d0w + (lane >> 3) + 8 * j], v);
-    }
-  }
 }
 
 // What the sequential backward assumes beyond what simamba_selective_scan_bwd has already checked: 16 states,

@@ -77,8 +77,9 @@ class Mamba(nn.Module):
         self.D._no_weight_decay = True
         self.out_proj = nn.Linear(self.d_inner, self.d_model, bias=bias, **factory_kwargs)
 
-    def forward(self, hidden_states, inference_params=None):
-        """hidden_states: (B, L, d_model) -> (B, L, d_model)."""
+    def forward(self, hidden_states, inference_params=None, A=None):
+        """hidden_states: (B, L, d_model) -> (B, L, d_model).  ``A`` (optional, beyond upstream's signature):
+        -exp(A_log) when the caller has already formed it (block.MixerModel does, for all layers at once)."""
         if inference_params is not None:
             raise NotImplementedError(
                 "step-wise decoding caches are not on the SI-Mamba path (no reference runner passes "
@@ -86,8 +87,7 @@ class Mamba(nn.Module):
         batch, seqlen, _ = hidden_states.shape
         # (2D, d) @ (B, d, L) -> (B, 2D, L): L is the contiguous axis the HIP kernels stream along
         if self.use_fast_path:
-            return self.forward_xz(self.in_proj_xz(hidden_states))
-        A = self.__dict__.pop("_A_pre", None)
+            return self.forward_xz(self.in_proj_xz(hidden_states), A=A)
         if A is None:
             A = -torch.exp(self.A_log.float())
         # reference composition of the separate ops (same kernels; torch.matmul / chunk copy the views)
@@ -110,13 +110,12 @@ class Mamba(nn.Module):
         """(B, L, d_model) -> xz (B, 2 d_inner, L), L contiguous: the in_proj half of forward()."""
         return in_proj_fn(hidden_states, self.in_proj.weight, self.in_proj.bias)
 
-    def forward_xz(self, xz):
+    def forward_xz(self, xz, A=None):
         """xz (B, 2 d_inner, L) -> (B, L, d_model): everything after in_proj as one autograd node, no
         activation-sized copies (mamba_inner.py).  forward(h) == forward_xz(in_proj_xz(h)); MixerModel calls the two
         halves separately for the first block when the sequence is an expansion of fewer distinct tokens
         (seq_expand.py)."""
-        A = self.__dict__.pop("_A_pre", None)               # MixerModel computes -exp(A_log) of all its layers at once
-        if A is None:
+        if A is None:                                       # MixerModel hands over -exp(A_log) of all its layers at once
             A = -torch.exp(self.A_log.float())
         return mamba_inner_fn(xz, self.conv1d.weight, self.conv1d.bias, self.x_proj.weight,
                               self.dt_proj.weight, self.out_proj.weight, self.out_proj.bias, A,

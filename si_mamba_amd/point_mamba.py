@@ -249,7 +249,7 @@ class PointMamba(nn.Module):
         if idx is not None and not (self.training and self.drop_out.p > 0):
             # the sequence is a gather of the G patch tokens: the stack takes the distinct tokens plus the index map
             # and runs the first block's per-token head on G instead of L positions (seq_expand.py); same result
-            x = self.blocks(tokens, pos, token_index=idx)
+            x = self.blocks(tokens, pos, token_index=idx, balanced_index=True)     # concatenated permutations
         else:
             x, pos = self.order_tokens(tokens, pos, center, order)
             x = self.drop_out(x)

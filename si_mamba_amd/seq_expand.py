@@ -20,8 +20,11 @@ from . import _lib
 
 
 def inverse_positions(token_index, G):
-    """(B, L) token of every sequence position -> (B, G, R) int32 positions of every token, or None when the tokens
-    do not all occur equally often (R = L / G times): then the adjoint kernel does not apply."""
+    """(B, L) token of every sequence position -> (B, G, R) int32 positions of every token.  PRECONDITION (the caller's
+    to state, MixerModel.forward(balanced_index=True)): every token occurs exactly R = L / G times in every row -- a
+    concatenation of permutations.  With unequal counts the grouping below would put positions into the wrong tokens'
+    rows and the adjoint kernel would sum the wrong gradients; checking it here would cost a device synchronisation
+    per forward, so it is a contract, enforced in the tests (tests/test_gpu_model.py).  None when L % G != 0."""
     B, L = token_index.shape
     if L % G:
         return None

@@ -377,7 +377,7 @@ def test_first_block_on_distinct_tokens_equals_reference_route(device):
     seq_expand.seq_gather_last = lambda *x: (calls.append(1), real(*x))[1]
     try:
         ta, pa = tokens.clone().requires_grad_(True), pos.clone().requires_grad_(True)
-        oa = a(ta, pa, token_index=idx)
+        oa = a(ta, pa, token_index=idx, balanced_index=True)
     finally:
         seq_expand.seq_gather_last = real
     assert calls, "the distinct-token route was not taken"
@@ -391,13 +391,30 @@ def test_first_block_on_distinct_tokens_equals_reference_route(device):
     assert nerr(ta.grad, tb.grad) < 1e-4 and nerr(pa.grad, pb.grad) < 1e-4
     for (ka, qa), (_, qb) in zip(a.named_parameters(), b.named_parameters()):
         assert nerr(qa.grad, qb.grad) < 1e-4, ka
-    # an index in which the tokens do not occur equally often falls back to the reference's route
+    # Any index the caller has not declared balanced (every token exactly L / G times per row) takes the reference's
+    # route: here one token is duplicated and one missing -- with the distinct-token adjoint this would sum the wrong
+    # positions.  Outputs AND gradients, against the reference composition.
     idx2 = idx.clone()
     idx2[:, 0] = idx2[:, 1]
-    with torch.no_grad():
-        o2 = a(tokens, pos, token_index=idx2)
-        ex2 = idx2.unsqueeze(-1).expand(-1, -1, 128)
-        assert nerr(o2, b(torch.gather(tokens, 1, ex2), torch.gather(pos, 1, ex2))) < 1e-5
+    calls.clear()
+    seq_expand.seq_gather_last = lambda *x: (calls.append(1), real(*x))[1]
+    try:
+        for mm in (a, b):
+            mm.zero_grad(set_to_none=True)
+        t2, p2 = tokens.clone().requires_grad_(True), pos.clone().requires_grad_(True)
+        o2 = a(t2, p2, token_index=idx2)
+    finally:
+        seq_expand.seq_gather_last = real
+    assert not calls, "an undeclared index must not take the distinct-token route"
+    t3, p3 = tokens.clone().requires_grad_(True), pos.clone().requires_grad_(True)
+    ex2 = idx2.unsqueeze(-1).expand(-1, -1, 128)
+    o3 = b(torch.gather(t3, 1, ex2), torch.gather(p3, 1, ex2))
+    (o2 * w).sum().backward()
+    (o3 * w).sum().backward()
+    assert nerr(o2, o3) < 1e-5
+    assert nerr(t2.grad, t3.grad) < 1e-4 and nerr(p2.grad, p3.grad) < 1e-4
+    for (ka, qa), (_, qb) in zip(a.named_parameters(), b.named_parameters()):
+        assert nerr(qa.grad, qb.grad) < 1e-4, ka
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -430,7 +447,7 @@ def test_stack_precomputed_A_matches_per_layer(device):
     a = MixerModel(d_model=128, n_layer=3, drop_path=0.).to(device)
     b = MixerModel(d_model=128, n_layer=3, drop_path=0.).to(device)
     b.load_state_dict(a.state_dict())
-    b._precompute_A = lambda: None                       # every mixer computes its own A
+    b._precompute_A = lambda: [None] * len(b.layers)      # every mixer computes its own A
     x = torch.randn(2, 64, 128, device=device)
     pos = torch.randn(2, 64, 128, device=device)
     ya, yb = a(x, pos), b(x, pos)
@@ -441,4 +458,13 @@ def test_stack_precomputed_A_matches_per_layer(device):
         assert p.grad is not None and q.grad is not None, k
         scale = max(q.grad.abs().max().item(), 1e-30)
         assert ((p.grad - q.grad).abs().max().item() / scale) < 1e-4, k
-    assert all("_A_pre" not in layer.mixer.__dict__ for layer in a.layers)     # every slice was consumed
+    # A travels as an argument: nothing is parked on the modules, so a forward that raises half way leaves no state
+    assert all("_A_pre" not in layer.mixer.__dict__ for layer in a.layers)
+    boom = a.layers[2].mixer.forward
+    a.layers[2].mixer.forward = lambda *x, **k: (_ for _ in ()).throw(RuntimeError("boom"))
+    with pytest.raises(RuntimeError, match="boom"):
+        a(x, pos)
+    a.layers[2].mixer.forward = boom
+    a.zero_grad(set_to_none=True)
+    assert torch.equal(a(x, pos), yb)                       # and the next forward is unaffected
+    assert torch.equal(a.layers[1](x, None)[0], b.layers[1](x, None)[0])       # a Block called on its own
