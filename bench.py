@@ -368,14 +368,20 @@ def main():
                 nb, msb = ktimes["scan_bwd"]
                 out["kernels"]["scan_bwd"]["GB/s"] = round(bb / msb / 1e6, 1)
                 # the backward is the larger HIP kernel of the step by time: same accounting, for completeness
+                ck = _lib.load().simamba_scan_ckpt_step(args.batch, D, L, N, _lib.F32 if s == 4 else _lib.BF16)
+                seq = ck == _lib.CKPT_SEQ
                 out["roofline_scan_bwd"] = {
                     "bound": "hbm", "achieved": round(bb / msb / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(bb / msb / 1e6 / HBM_PEAK_GBS, 4),
                     "traffic": traffic_from_profiles("scan_bwd", (args.batch, D, L, N)) if s == 4 else None,
-                    "kernel": f"scan_bwd_kernel<{'float' if s == 4 else 'bf16'},8>", "algorithmic_bytes": bb,
-                    "launches": nb, "mean_ms": round(msb, 4),
-                    "note": "VALU-bound (PMC: 27.6 VALU per (row, step, state), 76 % busy at 2 waves/SIMD, "
-                            "253 VGPRs); DESIGN.md 4.2"}
+                    "kernel": (f"scan_bwd_seq_kernel<{tname},true>" if seq else f"scan_bwd_kernel<{tname},8>"),
+                    "algorithmic_bytes": bb, "launches": nb, "mean_ms": round(msb, 4),
+                    "note": ("sequential lanes-per-channel backward (csrc/scan_bwd_seq.hip): VALU-bound, PMC: ~26 VALU "
+                             "per (row, step, state) at 91 % VALU-busy, 3 waves/SIMD; HBM traffic 1.24x the "
+                             "algorithmic bytes (16-step state checkpoints + dB/dC flush atomics); DESIGN.md 4.2"
+                             if seq else
+                             "row-scan backward: VALU-bound (27.6 VALU per (row, step, state), 76 % busy at 2 "
+                             "waves/SIMD); DESIGN.md 4.2")}
         if world == 1 and not args.no_headline:
             del opt
             torch.cuda.empty_cache()

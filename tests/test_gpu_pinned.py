@@ -91,7 +91,7 @@ def test_block_stack_on_hip_equals_reference_block_and_mixermodel(device):
     blk = model.layers[0]
     h, r = torch.from_numpy(g["block.h"]).to(device), torch.from_numpy(g["block.r"]).to(device)
     h1, r1 = blk(h, None)
-    assert nerr(h1, torch.from_numpy(g["block.first.h"])) < 1e-3 and torch.equal(r1.cpu(), torch.from_numpy(g["block.first.r"]))
+    assert nerr(h1, torch.from_numpy(g["block.first.h"])) < 1e-3 and torch.equal(r1.detach().cpu(), torch.from_numpy(g["block.first.r"]))
     h2, r2 = blk(h, r)
     assert nerr(h2, torch.from_numpy(g["block.next.h"])) < 1e-3
-    np.testing.assert_allclose(r2.cpu().numpy(), g["block.next.r"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(r2.detach().cpu().numpy(), g["block.next.r"], rtol=0, atol=1e-6)
