@@ -41,14 +41,36 @@ def scan_bwd_bytes(B, D, L, N, s=4):
     return 7 * B * D * L * s + 2 * B * N * L * (s + 4) + 8 * D * N + 16 * D
 
 
+SCAN_SOURCES = ("common.h", "scan_common.h", "scan_xlane.h", "scan_fwd.hip", "scan_fwd_seq.hip", "scan_bwd.hip",
+                "scan_bwd_seq.hip")
+
+
+def scan_sources_sha256():
+    """Hash of the scan kernels' sources: profiles/traffic.json records the one its PMC passes were taken on."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in SCAN_SOURCES:
+        with open(os.path.join(ROOT, "si_mamba_amd", "csrc", name), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def traffic_from_profiles(kernel, shape):
-    """HBM bytes per launch from the committed rocprofv3 PMC summary, if one matches (else null)."""
+    """(HBM bytes per launch, provenance) from the committed rocprofv3 PMC summary profiles/traffic.json -- a constant
+    measured by tools/pmc_traffic.sh, NOT measured in this run; (None, why) when no entry matches or when the scan
+    sources have changed since those passes were taken (the number would be stale)."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         rec = json.load(open(path))
-        return rec.get(f"{kernel}:{'x'.join(map(str, shape))}")
     except Exception:
-        return None
+        return None, "profiles/traffic.json unreadable"
+    val = rec.get(f"{kernel}:{'x'.join(map(str, shape))}")
+    if val is None:
+        return None, "no PMC entry for this kernel and shape in profiles/traffic.json"
+    if rec.get("_sources_sha256") != scan_sources_sha256():
+        return None, "profiles/traffic.json was measured on other scan sources (stale): re-run tools/pmc_traffic.sh"
+    return val, f"profiles/traffic.json ({rec.get('_measured', 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes')}); " \
+                "a committed constant, not measured in this run"
 
 
 def cpu_baseline(npts, groups, seed=0):
@@ -235,6 +257,8 @@ def main():
                          "choice, which is what every reported line uses)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-headline", action="store_true")
+    ap.add_argument("--no-bf16-step", action="store_true",
+                    help="skip the short bf16-autocast measurement that follows the timed fp32 region")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-tuned-gemm", action="store_true",
                     help="library-default GEMM solutions instead of si_mamba_amd/tuned/gemm_gfx950.csv")
@@ -275,7 +299,7 @@ def main():
     gt = torch.randint(0, cfg.cls_dim, (args.batch,), generator=torch.Generator().manual_seed(rank)).to(device)
     amp = torch.autocast("cuda", dtype=torch.bfloat16, enabled=(args.dtype == "bf16"))
 
-    def step():
+    def step(amp=amp):
         opt.zero_grad(set_to_none=True)
         with amp:
             logits = ddp(pts)
@@ -318,6 +342,30 @@ def main():
     _lib.enable_kernel_timing(False)
     assert torch.isfinite(loss).item(), "non-finite loss in the timed region"
 
+    # The same step under bf16 autocast (what the reference's pre-training and segmentation runners use,
+    # tools/runner_pretrain.py:243), measured AFTER the timed region so that the driver's record carries it: not the
+    # headline, same model / data / optimizer state continued, 3 warm-up + 10 timed steps, max over ranks.
+    bf16_step = None
+    if args.dtype == "f32" and not args.no_bf16_step:
+        amp16 = torch.autocast("cuda", dtype=torch.bfloat16)
+        for _ in range(3):
+            step(amp16)
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(10):
+            loss16 = step(amp16)
+        sync()
+        el16 = time.perf_counter() - t1
+        if world > 1:
+            te = torch.tensor([el16], device=device, dtype=torch.float64)
+            dist.all_reduce(te, op=dist.ReduceOp.MAX)
+            el16 = te.item()
+        bf16_step = {"value": round(args.batch * world * 10 / el16, 2), "unit": "point-clouds/s",
+                     "ms_per_step": round(1e2 * el16, 3), "steps": 10, "warmup": 3,
+                     "dtype": "bf16 autocast (parameters, optimizer, reductions, scan state fp32)",
+                     "finite_loss": bool(torch.isfinite(loss16).item()),
+                     "note": "measured after the timed fp32 region on the same model and data; not the headline"}
+
     if rank == 0:
         L = 2 * cfg.k_top_eigenvectors * args.groups
         D, N = 2 * cfg.trans_dim, 16
@@ -334,6 +382,8 @@ def main():
                        "global_batch": args.batch * world, "per_gpu_batch": args.batch,
                        "npoints": args.npoints, "patches": args.groups, "mamba_seq_len": L,
                        "parallelism": f"dp{world}",
+                       "dist_backend": (dist.get_backend() if world > 1 else None),
+                       "communicator_ranks": (dist.get_world_size() if world > 1 else 1),
                        "library_gemm": "tuned solution table (si_mamba_amd/tuned/gemm_gfx950.csv)" if tuned
                        else "library defaults"},
         }
@@ -344,14 +394,17 @@ def main():
             rows = args.batch * D
             tname = "float" if s == 4 else "bf16"
             auto = _lib.load().simamba_scan_fwd_auto_variant(args.batch, D)        # the library's own choice
+            # the in-step forward also writes the backward's checkpoints ("train" entries of traffic.json)
+            tr_f = traffic_from_profiles("scan_fwd_train", (args.batch, D, L, N)) if s == 4 else (None, "fp32 only")
             fwd_kernel = {_lib.SCAN_MIX: f"scan_fwd_seq_mix_kernel<{tname},true>",
                           _lib.SCAN_LPC2: f"scan_fwd_seq_kernel<{tname},true,2>",
                           _lib.SCAN_LPC4: f"scan_fwd_seq_kernel<{tname},true,4>"}.get(
                               auto, f"scan_fwd_kernel<{tname},{16 if L >= 768 else 8}>")
             out["roofline"] = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(ach / HBM_PEAK_GBS, 4),
-                               "traffic": traffic_from_profiles("scan_fwd", (args.batch, D, L, N)) if s == 4 else None,
+                               "traffic": tr_f[0], "traffic_source": tr_f[1],
                                "kernel": fwd_kernel,
+                               "kernel_source": "derived from simamba_scan_fwd_auto_variant(batch, dim), not observed",
                                "shape_BDLN": [args.batch, D, L, N], "algorithmic_bytes": nbytes,
                                "launches": n, "mean_ms": round(ms, 4),
                                "note": "VALU-bound on CDNA4, not HBM-bound (DESIGN.md 4.1): 5 VALU per (row, step, "
@@ -370,10 +423,11 @@ def main():
                 # the backward is the larger HIP kernel of the step by time: same accounting, for completeness
                 ck = _lib.load().simamba_scan_ckpt_step(args.batch, D, L, N, _lib.F32 if s == 4 else _lib.BF16)
                 seq = ck == _lib.CKPT_SEQ
+                tr_b = traffic_from_profiles("scan_bwd", (args.batch, D, L, N)) if s == 4 else (None, "fp32 only")
                 out["roofline_scan_bwd"] = {
                     "bound": "hbm", "achieved": round(bb / msb / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(bb / msb / 1e6 / HBM_PEAK_GBS, 4),
-                    "traffic": traffic_from_profiles("scan_bwd", (args.batch, D, L, N)) if s == 4 else None,
+                    "traffic": tr_b[0], "traffic_source": tr_b[1],
                     "kernel": (f"scan_bwd_seq_kernel<{tname},true>" if seq else f"scan_bwd_kernel<{tname},8>"),
                     "algorithmic_bytes": bb, "launches": nb, "mean_ms": round(msb, 4),
                     "note": ("sequential lanes-per-channel backward (csrc/scan_bwd_seq.hip): VALU-bound, PMC: ~26 VALU "
@@ -382,6 +436,8 @@ def main():
                              if seq else
                              "row-scan backward: VALU-bound (27.6 VALU per (row, step, state), 76 % busy at 2 "
                              "waves/SIMD); DESIGN.md 4.2")}
+        if bf16_step is not None:
+            out["bf16_step"] = bf16_step
         if world == 1 and not args.no_headline:
             del opt
             torch.cuda.empty_cache()

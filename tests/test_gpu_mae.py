@@ -128,3 +128,58 @@ def test_mae_train_step_reference_sizes(device):
            if not k.startswith("decoder_pos_embed.") and (p.grad is None or not torch.isfinite(p.grad).all())]
     assert not bad, bad
     assert all(p.grad is None for k, p in m.named_parameters() if k.startswith("decoder_pos_embed."))
+
+
+def test_config4_full_batch_step(device):
+    """BASELINE config 4 as a whole step at the per-GPU batch the metric names: B = 64 clouds of 1024 points -> 64
+    patches, mask 0.6, encoder L = 208 over 12 blocks, decoder L = 512 over 4 (cfgs/pretrain.yaml:37-68), in fp32 and
+    under bf16 autocast (tools/runner_pretrain.py:243).  Size-independent properties tie the full batch to the small
+    cases checked against the oracle (the ones config 3 uses, tests/test_gpu_model.py):
+      * eval-mode reconstructions of samples 0-1 inside the batch of 64 equal those of the model run on just those two
+        (same mask rows);
+      * with frozen statistics the summed Chamfer loss is additive over samples, so every parameter gradient of the
+        batch of 64 equals grad(first 32) + grad(last 32): the backward's batch reductions at two grid sizes -- at
+        these row counts (64 x 768 = 49 152) both scan directions run the lanes-per-channel kernels;
+      * the training-mode bf16 step (batch statistics, DropPath, random masks) gives a finite loss and gradients.
+    Tolerances: 1e-3 in fp32.  Under autocast the two sides of each comparison run DIFFERENT library GEMM kernels (the
+    batch size selects them) and every block rounds its activations to bf16, so they are held to 3e-2 -- the bf16
+    arithmetic itself is held to the oracle at 1e-2 by test_mae_forward_matches_oracle_flow."""
+    from compose import nerr as nerr1
+    from si_mamba_amd.mae import Point_MAE_Mamba, default_mae_config
+    torch.manual_seed(0)
+    cfg = default_mae_config()                      # DropPath / dropout at the config's rates: off in eval mode
+    m = Point_MAE_Mamba(cfg).to(device).eval()
+    B, G = 64, cfg.num_group
+    pts = _clouds(B, 1024, 41).to(device)
+    nm = int(cfg.transformer_config.mask_ratio * G)
+    gen = torch.Generator().manual_seed(6)
+    mask = (torch.rand(B, G, generator=gen).argsort(dim=1).argsort(dim=1) < nm).to(device)      # nm True per row
+    for on, tol in ((False, 1e-3), (True, 3e-2)):
+        amp = torch.autocast("cuda", dtype=torch.bfloat16, enabled=on)
+        with torch.no_grad(), amp:
+            _, full = m(pts, mask=mask, return_parts=True)
+            _, two = m(pts[:2], mask=mask[:2], return_parts=True)
+        assert full["x_vis"].shape == (B, 208, 384) and full["x_full"].shape == (B, 512, 384)
+        per = full["rebuild"].shape[0] // B
+        assert nerr1(full["rebuild"][:2 * per].float(), two["rebuild"].float()) < tol, on
+
+        def grads(sl):
+            m.zero_grad(set_to_none=True)
+            with amp:
+                loss, parts = m(pts[sl], mask=mask[sl], return_parts=True)
+            (loss * parts["rebuild"].shape[0]).backward()            # mean over (samples x masked patches) -> sum
+            return {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+
+        g_all, g_a, g_b = grads(slice(0, 64)), grads(slice(0, 32)), grads(slice(32, 64))
+        assert set(g_all) == set(g_a) == set(g_b) and len(g_all) > 100
+        for k in g_all:
+            assert nerr1(g_all[k], g_a[k] + g_b[k]) < tol, (on, k)
+    m.train()
+    m.zero_grad(set_to_none=True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        loss = m(pts)
+    loss.backward()
+    assert torch.isfinite(loss)
+    bad = [k for k, p in m.named_parameters()
+           if not k.startswith("decoder_pos_embed.") and (p.grad is None or not torch.isfinite(p.grad).all())]
+    assert not bad, bad
