@@ -147,6 +147,35 @@ int simamba_selective_scan_bwd(const void* u, const void* delta, const float* A,
                                long long bc_tstride, int ckpt_step, void* stream);
 
 /*
+ * The mixer's scan with delta formed INSIDE the scan kernels (no (batch, dim, seqlen) delta tensor exists): what
+ * upstream's mamba_inner_fn computes between x_proj and out_proj, reached from models/block.py:72.
+ *   u      : (batch, dim, seqlen) io_dtype -- the conv output
+ *   xdbl   : (batch, seqlen, dt_rank + 2 * 16) io_dtype, token-major -- the x_proj output [dt | B_t | C_t]; element
+ *            (b, t, s) at b * xdbl_bstride + t * xdbl_tstride + s (0 => contiguous)
+ *   wdt    : (dim, dt_rank) io_dtype -- dt_proj.weight
+ *   delta[b, d, t] = sum_r wdt[d, r] * xdbl[b, t, r] on the matrix pipe, with the instruction and k order of
+ *   simamba_xdt_proj_fwd: bit for bit the tensor that call would have stored (bf16: rounded to bf16 like it), then
+ *   out = (scan(u, softplus(delta + delta_bias), A, B_t, C_t) + D * u) * silu(z) exactly as simamba_selective_scan_fwd.
+ * Lanes-per-channel kernels only: dstate == 16, z required, dt_rank % 4 == 0 (bf16: % 8), 4 <= dt_rank <= 24, 16-byte
+ * aligned rows; anything else returns SIMAMBA_E_VARIANT / _SHAPE and the caller materialises delta
+ * (simamba_xdt_proj_fwd + simamba_selective_scan_fwd).  x_ckpt / ckpt_step / variant / last_state as in
+ * simamba_selective_scan_fwd (variant: AUTO, LPC2, LPC4 or MIX).
+ * Backward: the sequential kernel (16-step checkpoints of the forward, SIMAMBA_SCAN_CKPT_SEQ; dim % 64 == 0); outputs
+ * and accumulators as simamba_selective_scan_bwd, ddelta = gradient w.r.t. the delta formed above.
+ */
+int simamba_selective_scan_dt_fwd(const void* u, const void* xdbl, const void* wdt, const float* A, const float* D,
+                                  const void* z, const float* delta_bias, void* out, float* x_ckpt, float* last_state,
+                                  int batch, int dim, int seqlen, int dstate, int dt_rank, int io_dtype,
+                                  long long z_bstride, long long xdbl_bstride, long long xdbl_tstride, int ckpt_step,
+                                  int variant, void* stream);
+int simamba_selective_scan_dt_bwd(const void* u, const void* xdbl, const void* wdt, const float* A, const float* D,
+                                  const void* z, const float* delta_bias, const void* dout, const float* x_ckpt,
+                                  void* du, void* ddelta, float* dA, float* dB, float* dC, float* dD, void* dz,
+                                  float* ddelta_bias, int batch, int dim, int seqlen, int dstate, int dt_rank,
+                                  int io_dtype, long long z_bstride, long long dz_bstride, long long xdbl_bstride,
+                                  long long xdbl_tstride, void* stream);
+
+/*
  * Fused x_proj -> dt_proj of the mixer on the matrix cores (the two skinny GEMMs between the conv and the scan
  * inside upstream's mamba_inner_fn, reached from models/block.py:72):
  *   xdbl[b, t, s]  = sum_d wx[s, d] * x[b, d, t]            (batch, seqlen, S) token-major, S = dt_rank + 2 * dstate
@@ -158,6 +187,7 @@ int simamba_selective_scan_bwd(const void* u, const void* delta, const float* A,
  *   D % 64 == 0, D * seqlen * 4 < 2^32 (one sample is one buffer descriptor), seqlen % 4 == 0 (bf16: % 8), S % 4 == 0, S <= 64,
  *   R % 4 == 0, 4 <= R <= 24, 16-byte aligned pointers; anything else returns SIMAMBA_E_SHAPE / _ALIGN (the host
  *   mirror then takes the two library GEMMs).
+ *   delta == NULL: only xdbl (and xconv) are produced -- the delta product is left to simamba_selective_scan_dt_fwd.
  */
 int simamba_xdt_proj_fwd(const void* x, const void* wx, const void* wdt, void* xdbl, void* delta,
                          int batch, int D, int seqlen, int S, int R, int io_dtype, long long x_bstride,

@@ -45,6 +45,13 @@ SIGNATURES = {
                                            _P, _P, _P, _P, _P, _P, _P, _P,
                                            c_int, c_int, c_int, c_int, c_int, c_int,
                                            _LL, _LL, _LL, _LL, _LL, c_int, _P]),
+    "simamba_selective_scan_dt_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
+                                              c_int, c_int, c_int, c_int, c_int, c_int,
+                                              _LL, _LL, _LL, c_int, c_int, _P]),
+    "simamba_selective_scan_dt_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P,
+                                              _P, _P, _P, _P, _P, _P, _P, _P,
+                                              c_int, c_int, c_int, c_int, c_int, c_int,
+                                              _LL, _LL, _LL, _LL, _P]),
     "simamba_xdt_proj_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _LL, _P]),
     "simamba_conv_xdt_proj_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _LL,
                                           _P]),
@@ -223,6 +230,42 @@ class scan_ckpt:
     def __exit__(self, *exc):
         _scan_ckpt[0] = self.prev
         return False
+
+
+_fuse_dt = [None]      # None: the measured default (bf16 I/O only, see fuse_dt_enabled); True / False: forced
+counters = {}          # name -> how often a route was taken (tests assert on them; nothing in the product reads them)
+
+
+def count(name):
+    counters[name] = counters.get(name, 0) + 1
+
+
+
+class scan_fuse_dt:
+    """Context manager for benchmarks and parity tests: force the mixer to let the scan kernels form delta themselves
+    (simamba_selective_scan_dt_fwd / _bwd) wherever they can (True), or to materialise it as upstream does (False).
+    Production never enters it and gets the measured default of fuse_dt_enabled()."""
+
+    def __init__(self, on):
+        self.v, self.prev = (None if on is None else bool(on)), None
+
+    def __enter__(self):
+        self.prev, _fuse_dt[0] = _fuse_dt[0], self.v
+        return self
+
+    def __exit__(self, *exc):
+        _fuse_dt[0] = self.prev
+        return False
+
+
+def fuse_dt_enabled(dtype):
+    """Default: bf16 I/O only.  Measured at (64, 768, 1024), per layer, conv + x_proj (+ dt_proj) / scan forward / scan
+    backward (tools/bench_dt_fusion.py, profiles/r03b_dt_fusion.txt): bf16 96 + 315 + 691 us with delta materialised,
+    62 + 314 + 691 us formed in the scans (two bf16 MFMAs per tile: free); fp32 168 + 308 + 691 us against 126 + 356 +
+    790 us -- the exact-fp32 MFMA runs at the vector rate, and inside the VALU-bound scans its 12 instructions per tile
+    are additive, while inside the xdt kernel (bound by bytes in flight) they are hidden."""
+    import torch
+    return (dtype == torch.bfloat16) if _fuse_dt[0] is None else _fuse_dt[0]
 
 
 def scan_plan(batch, dim, seqlen, dstate, dtype, aligned, device, need_grad):

@@ -277,7 +277,8 @@ static int launch_bwd(const ScanArgs& a, hipStream_t s) {
 struct BwdSeqArgs;
 bool scan_bwd_seq_ok(int batch, int dim, int seqlen, int dstate, int softplus, int vec, long long z_bs, long long dz_bs,
                      bool has_z, int bc_mode, long long bc_ns, long long bc_ts);
-int scan_bwd_seq_dispatch(const ScanArgs& a, int io_dtype, int bc_mode, hipStream_t s);
+int scan_bwd_seq_dispatch(const ScanArgs& a, int io_dtype, int bc_mode, hipStream_t s, const void* dt = nullptr,
+                          const void* wdt = nullptr, long long dt_bs = 0, long long dt_ts = 0, int dt_rank = 0);
 int scan_fwd_seq_bc_mode(const void* B, const void* C, int io_dtype, long long bc_bs, long long bc_ns, long long bc_ts);
 
 }  // namespace simamba
@@ -286,14 +287,16 @@ using namespace simamba;
 
 static bool aligned16b(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-extern "C" int simamba_selective_scan_bwd(const void* u, const void* delta, const float* A, const void* B,
-                                          const void* C, const float* D, const void* z,
-                                          const float* delta_bias, const void* dout, const float* x_ckpt,
-                                          void* du, void* ddelta, float* dA, float* dB, float* dC, float* dD,
-                                          void* dz, float* ddelta_bias, int batch, int dim, int seqlen,
-                                          int dstate, int io_dtype, int delta_softplus, long long z_bstride,
-                                          long long dz_bstride, long long bc_bstride, long long bc_nstride,
-                                          long long bc_tstride, int ckpt_step, void* stream) {
+// dt != NULL: delta is formed inside the (sequential) kernel from the x_proj output; `delta` is then NULL
+static int scan_bwd_impl(const void* u, const void* delta, const float* A, const void* B,
+                         const void* C, const float* D, const void* z,
+                         const float* delta_bias, const void* dout, const float* x_ckpt,
+                         void* du, void* ddelta, float* dA, float* dB, float* dC, float* dD,
+                         void* dz, float* ddelta_bias, int batch, int dim, int seqlen,
+                         int dstate, int io_dtype, int delta_softplus, long long z_bstride,
+                         long long dz_bstride, long long bc_bstride, long long bc_nstride,
+                         long long bc_tstride, int ckpt_step, void* stream, const void* dt, const void* wdt,
+                         long long dt_bs, long long dt_ts, int dt_rank) {
   if (batch < 0 || dim <= 0 || seqlen < 0 || batch > 65535) return SIMAMBA_E_SHAPE;
   if (ckpt_step == 0) ckpt_step = SIMAMBA_SCAN_CKPT_ROW;
   if (ckpt_step != SIMAMBA_SCAN_CKPT_ROW && ckpt_step != SIMAMBA_SCAN_CKPT_SEQ) return SIMAMBA_E_VARIANT;
@@ -301,7 +304,7 @@ extern "C" int simamba_selective_scan_bwd(const void* u, const void* delta, cons
   if (io_dtype != SIMAMBA_F32 && io_dtype != SIMAMBA_BF16) return SIMAMBA_E_DTYPE;
   if (!A || !dA) return SIMAMBA_E_NULLPTR;
   if (batch > 0 && seqlen > 0) {
-    if (!u || !delta || !B || !C || !dout || !du || !ddelta || !dB || !dC) return SIMAMBA_E_NULLPTR;
+    if (!u || (!delta && !dt) || !B || !C || !dout || !du || !ddelta || !dB || !dC) return SIMAMBA_E_NULLPTR;
     if ((z != nullptr) != (dz != nullptr)) return SIMAMBA_E_NULLPTR;
   }
   const int nchunks = simamba_scan_num_chunks(seqlen);
@@ -348,7 +351,7 @@ extern "C" int simamba_selective_scan_bwd(const void* u, const void* delta, cons
     bc_bstride = static_cast<long long>(dstate) * seqlen; bc_nstride = seqlen; bc_tstride = 1;
   }
   a.bc_bs = bc_bstride; a.bc_ns = bc_nstride; a.bc_ts = bc_tstride;
-  a.vec = ((seqlen * esz) % 16 == 0) && aligned16b(u) && aligned16b(delta) && aligned16b(dout) &&
+  a.vec = ((seqlen * esz) % 16 == 0) && aligned16b(u) && (dt || aligned16b(delta)) && aligned16b(dout) &&
           aligned16b(du) && aligned16b(ddelta) &&
           (!z || (aligned16b(z) && aligned16b(dz) && (a.z_bs * esz) % 16 == 0 && (a.dz_bs * esz) % 16 == 0));
   if (ckpt_step == SIMAMBA_SCAN_CKPT_SEQ) {
@@ -357,8 +360,9 @@ extern "C" int simamba_selective_scan_bwd(const void* u, const void* delta, cons
                          a.bc_ns, a.bc_ts) ||
         (reinterpret_cast<uintptr_t>(A) & 15u) != 0 || (x_ckpt && (reinterpret_cast<uintptr_t>(x_ckpt) & 15u) != 0))
       return SIMAMBA_E_VARIANT;
-    return scan_bwd_seq_dispatch(a, io_dtype, bc_mode, s);
+    return scan_bwd_seq_dispatch(a, io_dtype, bc_mode, s, dt, wdt, dt_bs, dt_ts, dt_rank);
   }
+  if (dt) return SIMAMBA_E_VARIANT;                          // only the sequential kernel forms delta itself
   // channels per workgroup (16 * passes): the more, the fewer dB/dC atomics reach HBM (measured at
   // (64,768,1024,16): 134 MB of flush traffic at passes = 3, 18 % on top of the 604 MB of gradient stores);
   // but keep >= 2 workgroups per CU, the number resident at this kernel's register footprint.
@@ -369,4 +373,44 @@ extern "C" int simamba_selective_scan_bwd(const void* u, const void* delta, cons
   }
   a.passes = passes;
   return io_dtype == SIMAMBA_F32 ? launch_bwd<float>(a, s) : launch_bwd<bf16_t>(a, s);
+}
+
+extern "C" int simamba_selective_scan_bwd(const void* u, const void* delta, const float* A, const void* B,
+                                          const void* C, const float* D, const void* z,
+                                          const float* delta_bias, const void* dout, const float* x_ckpt,
+                                          void* du, void* ddelta, float* dA, float* dB, float* dC, float* dD,
+                                          void* dz, float* ddelta_bias, int batch, int dim, int seqlen,
+                                          int dstate, int io_dtype, int delta_softplus, long long z_bstride,
+                                          long long dz_bstride, long long bc_bstride, long long bc_nstride,
+                                          long long bc_tstride, int ckpt_step, void* stream) {
+  return scan_bwd_impl(u, delta, A, B, C, D, z, delta_bias, dout, x_ckpt, du, ddelta, dA, dB, dC, dD, dz, ddelta_bias,
+                       batch, dim, seqlen, dstate, io_dtype, delta_softplus, z_bstride, dz_bstride, bc_bstride,
+                       bc_nstride, bc_tstride, ckpt_step, stream, nullptr, nullptr, 0, 0, 0);
+}
+
+// Backward of simamba_selective_scan_dt_fwd: same operands (+ dout, the forward's 16-step checkpoints); ddelta is the
+// gradient with respect to the delta the kernels form (before bias and softplus), as in simamba_selective_scan_bwd.
+extern "C" int simamba_selective_scan_dt_bwd(const void* u, const void* xdbl, const void* wdt, const float* A,
+                                             const float* D, const void* z, const float* delta_bias, const void* dout,
+                                             const float* x_ckpt, void* du, void* ddelta, float* dA, float* dB,
+                                             float* dC, float* dD, void* dz, float* ddelta_bias, int batch, int dim,
+                                             int seqlen, int dstate, int dt_rank, int io_dtype, long long z_bstride,
+                                             long long dz_bstride, long long xdbl_bstride, long long xdbl_tstride,
+                                             void* stream) {
+  if (dstate != kMaxState) return SIMAMBA_E_DSTATE;
+  if (io_dtype != SIMAMBA_F32 && io_dtype != SIMAMBA_BF16) return SIMAMBA_E_DTYPE;
+  const int pack = io_dtype == SIMAMBA_F32 ? 4 : 8;
+  if (dt_rank < pack || dt_rank > 24 || dt_rank % pack) return SIMAMBA_E_SHAPE;
+  if (batch > 0 && seqlen > 0 && (!xdbl || !wdt || !z)) return SIMAMBA_E_NULLPTR;
+  const size_t esz = io_dtype == SIMAMBA_F32 ? 4 : 2;
+  const long long S = dt_rank + 2 * kMaxState;
+  const long long xb = xdbl_bstride ? xdbl_bstride : S * seqlen, xt = xdbl_tstride ? xdbl_tstride : S;
+  if (!aligned16b(xdbl) || !aligned16b(wdt) || (xb * esz) % 16 || (xt * esz) % 16 || (dt_rank * esz) % 16 ||
+      static_cast<long long>(batch) * xb >= (1ll << 30))
+    return SIMAMBA_E_VARIANT;
+  const char* Bp = static_cast<const char*>(xdbl) + static_cast<size_t>(dt_rank) * esz;
+  const char* Cp = Bp + kMaxState * esz;
+  return scan_bwd_impl(u, nullptr, A, Bp, Cp, D, z, delta_bias, dout, x_ckpt, du, ddelta, dA, dB, dC, dD, dz,
+                       ddelta_bias, batch, dim, seqlen, dstate, io_dtype, 1, z_bstride, dz_bstride, xb, 1, xt,
+                       SIMAMBA_SCAN_CKPT_SEQ, stream, xdbl, wdt, xb, xt, dt_rank);
 }

@@ -54,6 +54,10 @@ struct BwdSeqArgs {
   void* du; void* ddelta; void* dz;
   const float* A; const float* D; const float* delta_bias;
   const void* B; const void* C;
+  // kDt kernels: delta is formed here from the dt columns of the x_proj output, as in csrc/scan_fwd_seq.hip
+  const void* dt; const void* wdt;         // element (b, t, r) at b * dt_bs + t * dt_ts + r; (dim, dt_rank), I/O type
+  long long dt_bs, dt_ts;
+  int dt_rank;
   const float* ckpt;                       // (batch, nck, dim, 16)
   float* dA; float* dB; float* dC; float* dD; float* ddelta_bias;
   int batch, dim, seqlen, nck;
@@ -124,7 +128,10 @@ __device__ __forceinline__ void bs_quad_sum2(float& a, float& b) {
       : "+v"(a), "+v"(b));
 }
 
-template <typename T, bool kHasZ>
+using f32x4_t = __attribute__((ext_vector_type(4))) float;
+using bf16x8_t = __attribute__((ext_vector_type(8))) __bf16;
+
+template <typename T, bool kHasZ, bool kDt = false>
 __global__ __launch_bounds__(kBsThreads, SIMAMBA_BWDSEQ_OCC) void scan_bwd_seq_kernel(BwdSeqArgs p) {
   __shared__ __attribute__((aligned(16))) float smem[kBsSmemFloats];
   const int tid = threadIdx.x;
@@ -216,6 +223,53 @@ __global__ __launch_bounds__(kBsThreads, SIMAMBA_BWDSEQ_OCC) void scan_bwd_seq_k
   // operands of one chunk, requested one chunk ahead: the packs of the load layout, the biases of their rows and the
   // state entering the chunk's right segment
   float dv[2][4], uv[2][4], gv[2][4], zv[2][4], hsn[4], biasA[2];
+  // kDt: delta[step][channel] = sum_r dt[step][r] * wdt[channel][r] of the chunk as two 16 x 16 tiles of the matrix pipe
+  // (16 channels per wave): v_mfma_f32_16x16x4_f32, whose four k per instruction are chained in the order the forward's
+  // 32x32x2 pairs are -- r = 8 g, 8 g + 4, 8 g + 1, 8 g + 5, then 8 g + 2, + 6, + 3, + 7 -- so the values are the forward's
+  // bit for bit; bf16: one v_mfma_f32_16x16x32_bf16 per tile (r = 8 k .. + 7, zero past dt_rank), rounded to bf16.
+  // C/D layout: lane (column = channel l & 15, k = l >> 4) holds rows 4 k .. 4 k + 3: ONE pack of 4 steps per tile,
+  // dv[tile] = pack 4 tile + (l >> 4) of channel l & 15; biasA[0] its channel's bias.
+  auto form_delta = [&](int t0, int l) {
+    const int mc = l & 15, mk = l >> 4;
+    const T* wrow = static_cast<const T*>(p.wdt) + static_cast<size_t>(d0w + mc) * p.dt_rank;
+    biasA[0] = p.delta_bias ? p.delta_bias[d0w + mc] : 0.f;
+#pragma unroll
+    for (int tile = 0; tile < 2; ++tile) {
+      const int tt = t0 + 16 * tile + mc;
+      const T* dtrow = static_cast<const T*>(p.dt) + static_cast<long long>(b) * p.dt_bs +
+                       static_cast<long long>(tt < L ? tt : 0) * p.dt_ts;          // beyond the sequence: step 0
+      f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+      if constexpr (sizeof(T) == 4) {
+        const int c0 = (mk & 1) * 4 + (mk >> 1);
+        // all twelve loads go out unconditionally (clamped column, value zeroed afterwards): a predicated load makes
+        // hipcc drain vmcnt(0) before every use -- twenty-four serial L2 round trips per chunk instead of one
+        float a[6], w[6];
+#pragma unroll
+        for (int m = 0; m < 6; ++m) {
+          const int r = 8 * (m >> 1) + c0 + 2 * (m & 1);
+          const int rc = min(r, p.dt_rank - 1);
+          a[m] = reinterpret_cast<const float*>(dtrow)[rc];
+          w[m] = reinterpret_cast<const float*>(wrow)[rc];
+        }
+#pragma unroll
+        for (int m = 0; m < 6; ++m) {
+          const int r = 8 * (m >> 1) + c0 + 2 * (m & 1);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(r < p.dt_rank ? a[m] : 0.f, w[m], acc, 0, 0, 0);
+        }
+      } else {
+        const int kc = min(8 * mk, p.dt_rank - 8);           // dt_rank % 8 == 0; clamped, zeroed below (no predicated load)
+        uint4 a8 = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(dtrow) + kc);
+        const uint4 w8 = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(wrow) + kc);
+        if (8 * mk >= p.dt_rank) a8 = make_uint4(0u, 0u, 0u, 0u);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a8), __builtin_bit_cast(bf16x8_t, w8),
+                                                      acc, 0, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = bf16_to_f32(f32_to_bf16(acc[e]));
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dv[tile][e] = acc[e];
+    }
+  };
   auto load_state = [&](int ts) {                            // the forward's checkpoint at step ts - 1; zero at 0
     float4 h4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (ts > 0 && ts < L) h4 = *reinterpret_cast<const float4*>(ckl + static_cast<size_t>(ts / kBsSeg - 1) * D * kMaxState);
@@ -228,12 +282,13 @@ __global__ __launch_bounds__(kBsThreads, SIMAMBA_BWDSEQ_OCC) void scan_bwd_seq_k
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const unsigned ro = row_off(l, j) + to;
-      bs_load4<T>(dg, ro, dv[j]);
+      if (!kDt) bs_load4<T>(dg, ro, dv[j]);
       bs_load4<T>(ug, ro, uv[j]);
       bs_load4<T>(gg, ro, gv[j]);
       if (kHasZ) bs_load4<T>(zg, ro + zdelta, zv[j]);
-      biasA[j] = p.delta_bias ? p.delta_bias[d0w + (l >> 3) + 8 * j] : 0.f;
+      if (!kDt) biasA[j] = p.delta_bias ? p.delta_bias[d0w + (l >> 3) + 8 * j] : 0.f;
     }
+    if (kDt) form_delta(t0, l);
     load_state(t0 + kBsSeg);
   };
 
@@ -254,13 +309,25 @@ __global__ __launch_bounds__(kBsThreads, SIMAMBA_BWDSEQ_OCC) void scan_bwd_seq_k
     {
       const int l = lane_now();
       const bool in_seq = t0 + 4 * (l & 7) < L;
+      if (kDt) {                                             // delta in the accumulator's layout (form_delta)
+        const int mc = l & 15, mk = l >> 4;
+#pragma unroll
+        for (int tile = 0; tile < 2; ++tile) {
+          const int qm = 4 * tile + mk;
+          const float b2 = (t0 + 4 * qm < L) ? biasA[0] * kLog2e : -1e30f;
+          float dl[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) dl[i] = bs_softplus_log2(fmaf(dv[tile][i], kLog2e, b2));
+          *reinterpret_cast<float4*>(tD + bs_tile_off(mc, qm)) = make_float4(dl[0], dl[1], dl[2], dl[3]);
+        }
+      }
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const float b2 = in_seq ? biasA[j] * kLog2e : -1e30f;  // padded pack: softplus -> 0, the identity step
         float dl[4], dyv[4], dzw[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          dl[i] = bs_softplus_log2(fmaf(dv[j][i], kLog2e, b2));
+          if (!kDt) dl[i] = bs_softplus_log2(fmaf(dv[j][i], kLog2e, b2));
           const float go = in_seq ? gv[j][i] : 0.f;
           if (kHasZ) {
             const float z = zv[j][i], sg = sigmoid_f(z);
@@ -271,7 +338,7 @@ __global__ __launch_bounds__(kBsThreads, SIMAMBA_BWDSEQ_OCC) void scan_bwd_seq_k
           }
         }
         const int to_ = bs_tile_off((l >> 3) + 8 * j, l & 7);
-        *reinterpret_cast<float4*>(tD + to_) = make_float4(dl[0], dl[1], dl[2], dl[3]);
+        if (!kDt) *reinterpret_cast<float4*>(tD + to_) = make_float4(dl[0], dl[1], dl[2], dl[3]);
         *reinterpret_cast<float4*>(tU + to_) = make_float4(uv[j][0], uv[j][1], uv[j][2], uv[j][3]);
         *reinterpret_cast<float4*>(tY + to_) = make_float4(dyv[0], dyv[1], dyv[2], dyv[3]);
         if (kHasZ) *reinterpret_cast<float4*>(tZ + to_) = make_float4(dzw[0], dzw[1], dzw[2], dzw[3]);
@@ -513,7 +580,8 @@ bool scan_bwd_seq_ok(int batch, int dim, int seqlen, int dstate, int softplus, i
          bc_ns >= 0 && bc_ts >= 0 && (kMaxState - 1) * bc_ns + (seqlen - 1) * bc_ts < (1ll << 30);
 }
 
-int scan_bwd_seq_dispatch(const ScanArgs& sa, int io_dtype, int bc_mode, hipStream_t s) {
+int scan_bwd_seq_dispatch(const ScanArgs& sa, int io_dtype, int bc_mode, hipStream_t s, const void* dt, const void* wdt,
+                          long long dt_bs, long long dt_ts, int dt_rank) {
   BwdSeqArgs a{};
   a.u = sa.u; a.delta = sa.delta; a.z = sa.z; a.dout = sa.dout;
   a.du = sa.du; a.ddelta = sa.ddelta; a.dz = sa.dz;
@@ -523,7 +591,13 @@ int scan_bwd_seq_dispatch(const ScanArgs& sa, int io_dtype, int bc_mode, hipStre
   a.batch = sa.batch; a.dim = sa.dim; a.seqlen = sa.seqlen; a.nck = (sa.seqlen + kBsSeg - 1) / kBsSeg;
   a.bc_mode = bc_mode;
   a.z_bs = sa.z_bs; a.dz_bs = sa.dz_bs; a.bc_bs = sa.bc_bs; a.bc_ns = sa.bc_ns; a.bc_ts = sa.bc_ts;
+  a.dt = dt; a.wdt = wdt; a.dt_bs = dt_bs; a.dt_ts = dt_ts; a.dt_rank = dt_rank;
   dim3 grid(a.dim / kBsCh, a.batch);
+  if (a.dt) {                                                // the mixer's form: gated, delta formed in the kernel
+    if (io_dtype == SIMAMBA_F32) hipLaunchKernelGGL((scan_bwd_seq_kernel<float, true, true>), grid, dim3(kBsThreads), 0, s, a);
+    else hipLaunchKernelGGL((scan_bwd_seq_kernel<bf16_t, true, true>), grid, dim3(kBsThreads), 0, s, a);
+    return static_cast<int>(hipGetLastError());
+  }
   if (io_dtype == SIMAMBA_F32) {
     if (a.z) hipLaunchKernelGGL((scan_bwd_seq_kernel<float, true>), grid, dim3(kBsThreads), 0, s, a);
     else hipLaunchKernelGGL((scan_bwd_seq_kernel<float, false>), grid, dim3(kBsThreads), 0, s, a);

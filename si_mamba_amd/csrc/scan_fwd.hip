@@ -162,7 +162,9 @@ int scan_fwd_seq_dispatch(const void* u, const void* delta, const float* A, cons
                           const void* z, const float* delta_bias, void* out, float* x_ckpt, int ckpt_step,
                           float* last_state,
                           int batch, int dim, int seqlen, int io_dtype, long long z_bs,
-                          long long bc_bs, long long bc_ns, long long bc_ts, int nchunks128, int lpc, hipStream_t s);
+                          long long bc_bs, long long bc_ns, long long bc_ts, int nchunks128, int lpc, hipStream_t s,
+                          const void* dt = nullptr, const void* wdt = nullptr, long long dt_bs = 0, long long dt_ts = 0,
+                          int dt_rank = 0);
 int scan_fwd_seq_bc_mode(const void* B, const void* C, int io_dtype, long long bc_bs, long long bc_ns, long long bc_ts);
 int scan_fwd_seq_mix_c4(int batch, int dim);
 
@@ -282,4 +284,49 @@ extern "C" int simamba_selective_scan_fwd(const void* u, const void* delta, cons
   a.passes = passes;
   a.long_items = seqlen >= 768;   // measured: -6 % at L = 1024, neutral at L = 512 (3 instead of 4 waves per SIMD)
   return io_dtype == SIMAMBA_F32 ? launch_fwd<float>(a, s) : launch_fwd<bf16_t>(a, s);
+}
+
+// The mixer's scan with delta formed inside the kernel (csrc/scan_fwd_seq.hip, kDt): u = the conv output, xdbl = the
+// x_proj output (batch, seqlen, dt_rank + 2 * 16) token-major, wdt = dt_proj.weight (dim, dt_rank) in the I/O type.
+extern "C" int simamba_selective_scan_dt_fwd(const void* u, const void* xdbl, const void* wdt, const float* A,
+                                             const float* D, const void* z, const float* delta_bias, void* out,
+                                             float* x_ckpt, float* last_state, int batch, int dim, int seqlen,
+                                             int dstate, int dt_rank, int io_dtype, long long z_bstride,
+                                             long long xdbl_bstride, long long xdbl_tstride, int ckpt_step, int variant,
+                                             void* stream) {
+  if (batch < 0 || dim <= 0 || seqlen < 0 || batch > 65535) return SIMAMBA_E_SHAPE;
+  if (dstate != kMaxState) return SIMAMBA_E_DSTATE;
+  if (io_dtype != SIMAMBA_F32 && io_dtype != SIMAMBA_BF16) return SIMAMBA_E_DTYPE;
+  if (ckpt_step == 0) ckpt_step = SIMAMBA_SCAN_CKPT_ROW;
+  if (ckpt_step != SIMAMBA_SCAN_CKPT_ROW && ckpt_step != SIMAMBA_SCAN_CKPT_SEQ) return SIMAMBA_E_VARIANT;
+  if (variant != SIMAMBA_SCAN_AUTO && variant != SIMAMBA_SCAN_LPC2 && variant != SIMAMBA_SCAN_LPC4 &&
+      variant != SIMAMBA_SCAN_MIX)
+    return SIMAMBA_E_VARIANT;                               // the row-scan kernel reads a delta tensor
+  const int pack = io_dtype == SIMAMBA_F32 ? 4 : 8;
+  if (dt_rank < pack || dt_rank > 24 || dt_rank % pack) return SIMAMBA_E_SHAPE;
+  if (batch == 0 || seqlen == 0) return SIMAMBA_OK;
+  if (!u || !xdbl || !wdt || !A || !z || !out) return SIMAMBA_E_NULLPTR;
+  const size_t esz = io_dtype == SIMAMBA_F32 ? 4 : 2;
+  const long long S = dt_rank + 2 * kMaxState;
+  const long long xb = xdbl_bstride ? xdbl_bstride : S * seqlen, xt = xdbl_tstride ? xdbl_tstride : S;
+  const long long zb = z_bstride ? z_bstride : static_cast<long long>(dim) * seqlen;
+  const long long rows = static_cast<long long>(batch) * dim;
+  const char* Bp = static_cast<const char*>(xdbl) + static_cast<size_t>(dt_rank) * esz;
+  const char* Cp = Bp + kMaxState * esz;
+  const bool ok = ((seqlen * esz) % 16 == 0) && aligned16(u) && aligned16(out) && aligned16(z) && aligned16(xdbl) &&
+                  aligned16(wdt) && aligned16(A) && (zb * esz) % 16 == 0 && (xb * esz) % 16 == 0 &&
+                  (xt * esz) % 16 == 0 && (dt_rank * esz) % 16 == 0 && rows * seqlen < (1ll << 30) &&
+                  static_cast<long long>(batch) * zb < (1ll << 30) && static_cast<long long>(batch) * xb < (1ll << 30) &&
+                  scan_fwd_seq_bc_mode(Bp, Cp, io_dtype, xb, 1, xt) == 2;
+  if (!ok) return SIMAMBA_E_VARIANT;
+  int v = variant;
+  if (v == SIMAMBA_SCAN_AUTO) {
+    v = auto_variant(rows, batch, dim);
+    if (v == SIMAMBA_SCAN_ROWSCAN) v = SIMAMBA_SCAN_LPC4;   // too few rows for two lanes per channel
+  }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return scan_fwd_seq_dispatch(u, nullptr, A, Bp, Cp, D, z, delta_bias, out, x_ckpt, ckpt_step, last_state, batch, dim,
+                               seqlen, io_dtype, zb, xb, 1, xt, simamba_scan_num_chunks(seqlen),
+                               v == SIMAMBA_SCAN_MIX ? 6 : v == SIMAMBA_SCAN_LPC2 ? 2 : 4, s,
+                               xdbl, wdt, xb, xt, dt_rank);
 }

@@ -48,6 +48,13 @@ struct SeqArgs {
   const float* delta_bias;
   const void* B;
   const void* C;
+  // kDt kernels: delta is not read but formed here, delta[d][t] = sum_r wdt[d][r] * dt[t][r], from the dt columns of
+  // the x_proj output (token-major rows, the same rows B_t | C_t are staged from) -- csrc/xdt_proj.hip then skips
+  // its delta phase and the tensor never exists
+  const void* dt;                          // element (b, t, r) at b * dt_bs + t * dt_ts + r
+  const void* wdt;                         // (dim, dt_rank), I/O type
+  long long dt_bs, dt_ts;
+  int dt_rank;
   float* x_ckpt;
   float* ckpt16;                           // state at every 16-step boundary, (batch, nck16, dim, 16): what the
   int nck16;                               // sequential backward (scan_bwd_seq.hip) starts its segments from
@@ -125,7 +132,10 @@ template <int kLPC> struct SeqCfg {
 };
 
 // One wave's work: channels ch_base .. ch_base + R of sample b, the whole sequence.  tD: the wave's LDS tiles.
-template <typename T, bool kHasZ, int kLPC>
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+
+template <typename T, bool kHasZ, int kLPC, bool kDt = false>
 __device__ __forceinline__ void seq_body(const SeqArgs& p, const int b, const int ch_base, float* tD) {
   typedef SeqCfg<kLPC> Cfg;
   constexpr int NS = Cfg::NS, R = Cfg::R, kPacks = Cfg::kPacks;
@@ -223,14 +233,63 @@ __device__ __forceinline__ void seq_body(const SeqArgs& p, const int b, const in
     const unsigned toff = (t0 + 4 * q < L) ? t0 * kEsz : 0u - 4u * q * kEsz;
 #pragma unroll
     for (int j = 0; j < kPacks; ++j) {
-      load4<T>(dg, rowoff[j] + toff, dv[j]);
+      if (!kDt) load4<T>(dg, rowoff[j] + toff, dv[j]);
       load4<T>(ug, rowoff[j] + toff, uv[j]);
+    }
+  };
+
+  // ---- kDt: delta of a chunk on the matrix pipe ---------------------------------------------------------------------
+  // out[i = step][j = channel] = sum_r dt[step][r] * wdt[channel][r] as ONE 32 x 32 tile per wave and chunk:
+  // v_mfma_f32_32x32x2_f32 (exact fp32: a k-ordered fmaf chain) with the k order of csrc/xdt_proj.hip's delta product
+  // -- MFMA m = 4 g + e contracts r = 8 g + e (lanes < 32) then r = 8 g + 4 + e (lanes >= 32) -- so the values are bit
+  // for bit the ones that kernel stored; bf16: two v_mfma_f32_32x32x16_bf16 (r = 16 j + 8 h .. + 7, zero past dt_rank)
+  // and one rounding to bf16, as csrc/xdt_proj_bf16.hip does.  C/D layout: lane (column j = lane & 31, half h) holds rows
+  // 8 g' + 4 h + e in register 4 g' + e: four whole 4-step packs (2 g' + h) of ONE channel -- the shape phase A wants.
+  // With four lanes per channel the wave has 16 channels: columns 16-31 repeat them and are not stored.
+  const float biasM = (kDt && p.delta_bias) ? p.delta_bias[min(ch_base + ((lane & 31) % R), D - 1)] * kLog2e : 0.f;
+  f32x16 dacc;
+  auto form_delta = [&](int t0) {
+    const int mj = lane_v & 31, mh = lane_v >> 5;            // from the opaque lane id: nothing of this is loop-carried
+    const int d_m = min(ch_base + (mj % R), D - 1);
+    const int t = (t0 + mj < L) ? t0 + mj : 0;               // beyond the sequence: step 0 (its delta is overridden)
+    const T* dtrow = static_cast<const T*>(p.dt) + static_cast<long long>(b) * p.dt_bs + static_cast<long long>(t) * p.dt_ts;
+    const T* wrow = static_cast<const T*>(p.wdt) + static_cast<size_t>(d_m) * p.dt_rank;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dacc[i] = 0.f;
+    if constexpr (sizeof(T) == 4) {
+      float a[12], w[12];
+#pragma unroll
+      for (int g = 0; g < 3; ++g) {
+        // unconditional loads (clamped column group, zeroed afterwards): a predicated load makes hipcc drain vmcnt(0)
+        // before every use.  dt_rank % 4 == 0: four r are all in or all out
+        const int rc = min(8 * g + 4 * mh, p.dt_rank - 4);
+        float4 a4 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(dtrow) + rc);
+        const float4 w4 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(wrow) + rc);
+        if (8 * g + 4 * mh >= p.dt_rank) a4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        a[4 * g] = a4.x; a[4 * g + 1] = a4.y; a[4 * g + 2] = a4.z; a[4 * g + 3] = a4.w;
+        w[4 * g] = w4.x; w[4 * g + 1] = w4.y; w[4 * g + 2] = w4.z; w[4 * g + 3] = w4.w;
+      }
+#pragma unroll
+      for (int m = 0; m < 12; ++m) dacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], w[m], dacc, 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int kc = min(16 * j + 8 * mh, p.dt_rank - 8);  // dt_rank % 8 == 0; clamped, zeroed below
+        uint4 a8 = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(dtrow) + kc);
+        const uint4 w8 = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(wrow) + kc);
+        if (16 * j + 8 * mh >= p.dt_rank) a8 = make_uint4(0u, 0u, 0u, 0u);
+        dacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a8), __builtin_bit_cast(bf16x8, w8),
+                                                      dacc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) dacc[i] = bf16_to_f32(f32_to_bf16(dacc[i]));   // delta is a bf16 tensor there
     }
   };
 
   const int nchunks = (L + kSeqTC - 1) / kSeqTC;
   issue_bc(0);
   issue_loads(0);
+  if (kDt) form_delta(0);
   for (int c = 0; c < nchunks; ++c) {
     const int t0 = c * kSeqTC;
     asm volatile("" : "+v"(lane_v));
@@ -239,17 +298,41 @@ __device__ __forceinline__ void seq_body(const SeqArgs& p, const int b, const in
     // ---- phase A: softplus(delta), u and the chunk's B | C into the tiles ------------------------------------
 #pragma unroll
     for (int j = 0; j < kPacks; ++j) {
-      const float b2 = in_seq ? biasA[j] : -1e30f;            // padded pack: softplus -> 0, the identity map
-      float dl[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) dl[i] = softplus_log2(fmaf(dv[j][i], kLog2e, b2));
       const int o = tile_off(prow + 8 * j, qv);
-      *reinterpret_cast<float4*>(tD + o) = make_float4(dl[0], dl[1], dl[2], dl[3]);
+      if (!kDt) {
+        const float b2 = in_seq ? biasA[j] : -1e30f;          // padded pack: softplus -> 0, the identity map
+        float dl[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dl[i] = softplus_log2(fmaf(dv[j][i], kLog2e, b2));
+        *reinterpret_cast<float4*>(tD + o) = make_float4(dl[0], dl[1], dl[2], dl[3]);
+      }
       *reinterpret_cast<float4*>(tU + o) = make_float4(uv[j][0], uv[j][1], uv[j][2], uv[j][3]);
     }
+    if (kDt) {                                                // delta from the accumulator: packs 2 g' + h of channel mj
+      const int mj = lane_v & 31, mh = lane_v >> 5;
+      const bool m_valid = mj < R;
+#pragma unroll
+      for (int gp = 0; gp < 4; ++gp) {
+        const int qm = 2 * gp + mh;
+        const float b2 = (t0 + 4 * qm < L) ? biasM : -1e30f;
+        float dl[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dl[e] = softplus_log2(fmaf(dacc[4 * gp + e], kLog2e, b2));
+        if (m_valid) *reinterpret_cast<float4*>(tD + tile_off(mj, qm)) = make_float4(dl[0], dl[1], dl[2], dl[3]);
+      }
+    }
     stage_bc_tile();
-    // dv / uv are dead after phase A: the next chunk's loads fly during the whole recurrence
-    if (c + 1 < nchunks) issue_loads(t0 + kSeqTC);
+    // dv / uv are dead after phase A: the next chunk's loads fly during the whole recurrence (kDt: its delta tile is
+    // formed now -- 12 MFMAs on operands that come from L2 -- and waits in 16 registers where dv waited)
+    // (kDt: unconditional -- the last iteration re-requests chunk 0, harmlessly: under `if (c + 1 < nchunks)` the PREVIOUS
+    // contents of the accumulator would stay alive through the whole recurrence as the other arm of a phi)
+    if (kDt) {
+      const int tn = (c + 1 < nchunks) ? t0 + kSeqTC : 0;
+      form_delta(tn);
+      issue_loads(tn);
+    } else if (c + 1 < nchunks) {
+      issue_loads(t0 + kSeqTC);
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
@@ -365,8 +448,10 @@ __device__ __forceinline__ void seq_body(const SeqArgs& p, const int b, const in
   }
 }
 
-template <typename T, bool kHasZ, int kLPC>
-__global__ __launch_bounds__(kSeqThreads, SeqCfg<kLPC>::kWaves) void scan_fwd_seq_kernel(SeqArgs p) {
+// (four lanes per channel with the delta tile: its 32 x 32 accumulator is 16 registers where the 16-channel wave kept 8
+// of loaded delta -- held to three waves per SIMD instead of spilling at four)
+template <typename T, bool kHasZ, int kLPC, bool kDt = false>
+__global__ __launch_bounds__(kSeqThreads, SeqCfg<kLPC>::kWaves - ((kDt && kLPC == 4) ? 1 : 0)) void scan_fwd_seq_kernel(SeqArgs p) {
   typedef SeqCfg<kLPC> Cfg;
   __shared__ __attribute__((aligned(16))) float sMem[kSeqThreads / 64][Cfg::kTileFloats];
   int tile_id, b;
@@ -374,7 +459,7 @@ __global__ __launch_bounds__(kSeqThreads, SeqCfg<kLPC>::kWaves) void scan_fwd_se
   const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);   // SGPR
   const int ch_base = (tile_id * (kSeqThreads / 64) + wave) * Cfg::R;  // first channel of this wave
   if (ch_base >= p.dim) return;                                        // whole wave idle (no barriers here)
-  seq_body<T, kHasZ, kLPC>(p, b, ch_base, &sMem[wave][0]);
+  seq_body<T, kHasZ, kLPC, kDt>(p, b, ch_base, &sMem[wave][0]);
 }
 
 // Both forms in one launch of one-wave workgroups: the first dim - mix_c4 channels of every sample two lanes per
@@ -390,7 +475,7 @@ __global__ __launch_bounds__(kSeqThreads, SeqCfg<kLPC>::kWaves) void scan_fwd_se
 // delta): there the launch competes with that write-back for HBM and finishing the same bytes in less time is not
 // available.  Inside the model: 347 us against 302 us (rocprofv3).  So SIMAMBA_SCAN_AUTO does not pick it; it stays
 // an explicit variant with its parity tests.
-template <typename T, bool kHasZ>
+template <typename T, bool kHasZ, bool kDt = false>
 __global__ __launch_bounds__(64, SeqCfg<2>::kWaves) void scan_fwd_seq_mix_kernel(SeqArgs p) {
   __shared__ __attribute__((aligned(16))) float sMem[SeqCfg<2>::kTileFloats];
   const int g2 = (p.dim - p.mix_c4) / SeqCfg<2>::R, g4 = p.mix_c4 / SeqCfg<4>::R;   // waves per sample of each form
@@ -399,11 +484,11 @@ __global__ __launch_bounds__(64, SeqCfg<2>::kWaves) void scan_fwd_seq_mix_kernel
   const int n2 = bx * g2;
   if (k < n2) {
     const int sample = k / g2;
-    seq_body<T, kHasZ, 2>(p, x * bx + sample, (k - sample * g2) * SeqCfg<2>::R, sMem);
+    seq_body<T, kHasZ, 2, kDt>(p, x * bx + sample, (k - sample * g2) * SeqCfg<2>::R, sMem);
   } else {
     k -= n2;
     const int sample = k / g4;
-    seq_body<T, kHasZ, 4>(p, x * bx + sample, p.dim - p.mix_c4 + (k - sample * g4) * SeqCfg<4>::R, sMem);
+    seq_body<T, kHasZ, 4, kDt>(p, x * bx + sample, p.dim - p.mix_c4 + (k - sample * g4) * SeqCfg<4>::R, sMem);
   }
 }
 
@@ -411,6 +496,10 @@ template <typename T, int kLPC>
 static void launch_seq_lpc(const SeqArgs& a, hipStream_t s) {
   const int ch_per_wg = (kSeqThreads / 64) * SeqCfg<kLPC>::R;
   dim3 grid((a.dim + ch_per_wg - 1) / ch_per_wg, a.batch);
+  if (a.dt) {                                              // the mixer's form: gated, delta formed in the kernel
+    hipLaunchKernelGGL((scan_fwd_seq_kernel<T, true, kLPC, true>), grid, dim3(kSeqThreads), 0, s, a);
+    return;
+  }
   if (a.z)
     hipLaunchKernelGGL((scan_fwd_seq_kernel<T, true, kLPC>), grid, dim3(kSeqThreads), 0, s, a);
   else
@@ -452,8 +541,10 @@ int scan_fwd_seq_dispatch(const void* u, const void* delta, const float* A, cons
                           const void* z, const float* delta_bias, void* out, float* x_ckpt, int ckpt_step,
                           float* last_state,
                           int batch, int dim, int seqlen, int io_dtype, long long z_bs,
-                          long long bc_bs, long long bc_ns, long long bc_ts, int nchunks128, int lpc, hipStream_t s) {
+                          long long bc_bs, long long bc_ns, long long bc_ts, int nchunks128, int lpc, hipStream_t s,
+                          const void* dt, const void* wdt, long long dt_bs, long long dt_ts, int dt_rank) {
   SeqArgs a{};
+  a.dt = dt; a.wdt = wdt; a.dt_bs = dt_bs; a.dt_ts = dt_ts; a.dt_rank = dt_rank;
   a.u = u; a.delta = delta; a.z = z; a.out = out; a.A = A; a.D = D; a.delta_bias = delta_bias;
   a.B = B; a.C = C;
   if (ckpt_step == SIMAMBA_SCAN_CKPT_SEQ) { a.ckpt16 = x_ckpt; a.nck16 = (seqlen + 15) / 16; }
@@ -468,6 +559,11 @@ int scan_fwd_seq_dispatch(const void* u, const void* delta, const float* A, cons
     a.mix_c4 = scan_fwd_seq_mix_c4(batch, dim);
     if (a.mix_c4 == 0) return SIMAMBA_E_VARIANT;
     const unsigned grid = static_cast<unsigned>(batch) * ((dim - a.mix_c4) / SeqCfg<2>::R + a.mix_c4 / SeqCfg<4>::R);
+    if (a.dt) {
+      if (io_dtype == SIMAMBA_F32) hipLaunchKernelGGL((scan_fwd_seq_mix_kernel<float, true, true>), dim3(grid), dim3(64), 0, s, a);
+      else hipLaunchKernelGGL((scan_fwd_seq_mix_kernel<bf16_t, true, true>), dim3(grid), dim3(64), 0, s, a);
+      return static_cast<int>(hipGetLastError());
+    }
     if (io_dtype == SIMAMBA_F32) {
       if (z) hipLaunchKernelGGL((scan_fwd_seq_mix_kernel<float, true>), dim3(grid), dim3(64), 0, s, a);
       else hipLaunchKernelGGL((scan_fwd_seq_mix_kernel<float, false>), dim3(grid), dim3(64), 0, s, a);

@@ -311,6 +311,9 @@ __global__ __launch_bounds__(kXdtThreads, 2) void xdt_proj_f32_kernel(XdtArgs p)
     // prologue: steps 0 and 1 staged, 2 and 3 in flight, operands of step 0 in registers
     issue(s0, cm);
     issue(s1, cr);
+    // every load above has landed before the first conv reads its neighbours' packs through DPP: the one place where a
+    // miscounted wait (hipcc's waterfall loops) would go unnoticed; paid once per workgroup
+    if (kConv) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     stage(s0, cm, 0);
     issue(s0, cs);
     stage(s1, cr, 1);
@@ -342,8 +345,9 @@ __global__ __launch_bounds__(kXdtThreads, 2) void xdt_proj_f32_kernel(XdtArgs p)
   };
   using T = std::true_type;
   using F = std::false_type;
+  const bool want_delta = p.delta != nullptr;             // NULL: the scan forms delta itself (csrc/scan_fwd_seq.hip)
   for (int j = 0; j < ntw; ++j) {
-    if (j == 0) {
+    if (j == 0 || !want_delta) {
       for (int k = 0; k < nk; k += 2) {                    // nk is even: a tile starts on an even step
         iteration(o0, s0, 0, F{}, F{});
         iteration(o0, s1, 1, T{}, F{});
@@ -391,7 +395,7 @@ __global__ __launch_bounds__(kXdtThreads, 2) void xdt_proj_f32_kernel(XdtArgs p)
   }
 
   // ---- tail: delta of the last tile --------------------------------------------------------------------------------
-  for (int u = 0; u < nunits; ++u) {
+  for (int u = 0; want_delta && u < nunits; ++u) {
     f32x16 o;
     if (!(u & 1)) wload(u);
     unit_mfma(u, o);
@@ -420,7 +424,7 @@ static int xdt_launch(const void* x, const float* cw, const float* cb, const voi
   if (batch == 0 || L == 0) return SIMAMBA_OK;
   const float* wx = static_cast<const float*>(wx_);
   const float* wdt = static_cast<const float*>(wdt_);
-  if (!x || !wx || !wdt || !xdbl || !delta || (conv && (!cw || !xconv))) return SIMAMBA_E_NULLPTR;
+  if (!x || !wx || !wdt || !xdbl || (conv && (!cw || !xconv))) return SIMAMBA_E_NULLPTR;   // delta may be NULL
   uintptr_t al = reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(wx) | reinterpret_cast<uintptr_t>(wdt) |
                  reinterpret_cast<uintptr_t>(xdbl) | reinterpret_cast<uintptr_t>(delta);
   if (conv) al |= reinterpret_cast<uintptr_t>(cw) | reinterpret_cast<uintptr_t>(xconv);
@@ -441,9 +445,12 @@ static int xdt_launch(const void* x, const float* cw, const float* cb, const voi
   if (ntiles > 0x7fffffffLL) return SIMAMBA_E_SHAPE;
   long long g = ntiles;
   if (ntiles > 512) {
-    long long per = (ntiles + 511) / 512;                  // tiles per workgroup at full residency
-    while (ntiles % per) ++per;                            // ... evened out (per divides ntiles)
-    g = ntiles / per;
+    // tiles per workgroup at full residency, evened out (per divides ntiles) when a divisor is near: a prime tile count
+    // must not collapse the grid to a few workgroups -- the kernel takes uneven counts (ntw), evenness is only tidier
+    const long long per0 = (ntiles + 511) / 512;
+    long long per = per0;
+    while (ntiles % per && per < 2 * per0) ++per;
+    g = (ntiles % per == 0) ? ntiles / per : 512;
   }
   dim3 grid(static_cast<unsigned>(g));
   if (conv)

@@ -253,6 +253,7 @@ __global__ __launch_bounds__(kHThreads, 3) void xdt_proj_bf16_kernel(XdtHArgs p)
   {
     issue(s0, cm);
     issue(s1, cr);
+    if (kConv) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // as in xdt_proj.hip: before the first DPP conv
     stage(s0, cm, 0);
     issue(s0, cs);
     stage(s1, cr, 1);
@@ -285,8 +286,9 @@ __global__ __launch_bounds__(kHThreads, 3) void xdt_proj_bf16_kernel(XdtHArgs p)
   };
   using T = std::true_type;
   using F = std::false_type;
+  const bool want_delta = p.delta != nullptr;             // NULL: the scan forms delta itself (csrc/scan_fwd_seq.hip)
   for (int j = 0; j < ntw; ++j) {
-    if (j == 0) {
+    if (j == 0 || !want_delta) {
       for (int k = 0; k < nk; k += 2) {
         iteration(o0, s0, 0, F{}, F{});
         iteration(o0, s1, 1, T{}, F{});
@@ -326,7 +328,7 @@ __global__ __launch_bounds__(kHThreads, 3) void xdt_proj_bf16_kernel(XdtHArgs p)
     }
     __syncthreads();
   }
-  for (int u = 0; u < nunits; ++u) {                       // tail: delta of the last tile
+  for (int u = 0; want_delta && u < nunits; ++u) {         // tail: delta of the last tile
     f32x16 o;
     if (!(u & 1)) wload(u);
     unit_mfma(u, o);
@@ -349,10 +351,11 @@ int xdt_launch_bf16(const void* x, const float* cw, const float* cb, const void*
   a.batch = batch; a.D = D; a.L = L; a.S = S; a.R = R; a.x_bs = x_bs;
   const long long ntiles = static_cast<long long>(batch) * ((L + kHTok - 1) / kHTok);
   long long g = ntiles;
-  if (ntiles > 768) {                                      // 3 workgroups per CU resident; even tile counts
-    long long per = (ntiles + 767) / 768;
-    while (ntiles % per) ++per;
-    g = ntiles / per;
+  if (ntiles > 768) {                                      // 3 workgroups per CU resident; even tile counts when a
+    const long long per0 = (ntiles + 767) / 768;           // divisor is near (never a collapsed grid: xdt_proj.hip)
+    long long per = per0;
+    while (ntiles % per && per < 2 * per0) ++per;
+    g = (ntiles % per == 0) ? ntiles / per : 768;
   }
   if (conv)
     hipLaunchKernelGGL(xdt_proj_bf16_kernel<true>, dim3(static_cast<unsigned>(g)), dim3(kHThreads), 0, stream, a);

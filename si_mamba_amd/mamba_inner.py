@@ -91,26 +91,27 @@ def xdt_proj_fused_ok(x, wx, wdt, conv=False):
             and R % 4 == 0 and 4 <= R <= 24 and S >= R and wdt.shape[0] == D and x.data_ptr() % 16 == 0)
 
 
-def xdt_proj_fwd(x, wx, wdt, conv=None):
+def xdt_proj_fwd(x, wx, wdt, conv=None, want_delta=True):
     """x (B, D, L) fp32 or bf16 (batch-strided views allowed), wx (S, D), wdt (D, R) -> x_dbl (B, L, S) token-major, delta
-    (B, D, L).  ``conv=(w (D, 4) fp32, bias (D) or None, out (B, D, L))``: the causal depthwise conv1d + SiLU is applied
-    to x on the way in and its result written to ``out``.  No autograd: called from inside MambaInnerFn.forward, whose
-    backward differentiates the products itself."""
+    (B, D, L) -- or None with ``want_delta=False``: the delta product is then left to the scan kernels
+    (simamba_selective_scan_dt_fwd).  ``conv=(w (D, 4) fp32, bias (D) or None, out (B, D, L))``: the causal depthwise
+    conv1d + SiLU is applied to x on the way in and its result written to ``out``.  No autograd: called from inside
+    MambaInnerFn.forward, whose backward differentiates the products itself."""
     lib = _lib.load()
     Bsz, D, L = x.shape
     S, R = wx.shape[0], wdt.shape[1]
     wxc, wdc = wx.contiguous(), wdt.contiguous()
     x_dbl = torch.empty(Bsz, L, S, device=x.device, dtype=x.dtype)
-    delta = torch.empty(Bsz, D, L, device=x.device, dtype=x.dtype)
+    delta = torch.empty(Bsz, D, L, device=x.device, dtype=x.dtype) if want_delta else None
     with torch.cuda.device(x.device), _lib.timed("xdt_proj_fwd", x.device):
         if conv is None:
             rc = lib.simamba_xdt_proj_fwd(x.data_ptr(), wxc.data_ptr(), wdc.data_ptr(), x_dbl.data_ptr(),
-                                          delta.data_ptr(), Bsz, D, L, S, R, _lib.dtype_code(x.dtype), x.stride(0),
+                                          _lib.ptr(delta), Bsz, D, L, S, R, _lib.dtype_code(x.dtype), x.stride(0),
                                           _lib.stream_ptr(x.device))
         else:
             cw, cb, out = conv
             rc = lib.simamba_conv_xdt_proj_fwd(x.data_ptr(), cw.data_ptr(), _lib.ptr(cb), wxc.data_ptr(), wdc.data_ptr(),
-                                               out.data_ptr(), x_dbl.data_ptr(), delta.data_ptr(), Bsz, D, L, S, R,
+                                               out.data_ptr(), x_dbl.data_ptr(), _lib.ptr(delta), Bsz, D, L, S, R,
                                                _lib.dtype_code(x.dtype), x.stride(0), _lib.stream_ptr(x.device))
     _lib.check(rc, "simamba_xdt_proj_fwd")
     return x_dbl, delta
@@ -145,11 +146,22 @@ class MambaInnerFn(torch.autograd.Function):
         xw_c, dtw_c, ow_c = _w(x_proj_w, io), _w(dt_proj_w, io), _w(out_proj_w, io)   # compute-dtype weights,
         ctx.wcast = (xw_c, dtw_c, ow_c)                                               # reused by backward
         x_conv = torch.empty(Bsz, Dm, L, device=dev, dtype=io)
+        need_grad = any(ctx.needs_input_grad)
+        pack = 4 if io == torch.float32 else 8
+        aligned = xz.data_ptr() % 16 == 0 and (xbs * xz.element_size()) % 16 == 0
+        ckpt_step, x_ckpt = _lib.scan_plan(Bsz, Dm, L, N, io, aligned, dev, need_grad)
+        # Where both scan directions run the lanes-per-channel kernels (scan_plan: CKPT_SEQ) those kernels can form
+        # delta = dt_proj.weight @ dt themselves on the matrix pipe, and the (B, D, L) delta tensor never exists: one
+        # write and two reads of it per layer and step less (csrc/scan_fwd_seq.hip, csrc/scan_bwd_seq.hip).  Taken
+        # for bf16 I/O, where it is faster; measured slower in fp32 (_lib.fuse_dt_enabled)
+        fuse_dt = (_lib.fuse_dt_enabled(io) and ckpt_step == _lib.CKPT_SEQ and N == 16 and R % pack == 0 and R <= 24
+                   and _lib.current_scan_variant() != _lib.SCAN_ROWSCAN)
         if W == 4 and xdt_proj_fused_ok(x_in, xw_c, dtw_c, conv=True):
-            # conv1d + SiLU -> x_proj -> dt_proj as ONE pass over the x half of xz on the matrix cores
+            # conv1d + SiLU -> x_proj (-> dt_proj) as ONE pass over the x half of xz on the matrix cores
             # (csrc/xdt_proj.hip); x_conv is written as a by-product for the scan and the backward
-            x_dbl, delta = xdt_proj_fwd(x_in, xw_c, dtw_c, conv=(cw, cb, x_conv))
+            x_dbl, delta = xdt_proj_fwd(x_in, xw_c, dtw_c, conv=(cw, cb, x_conv), want_delta=not fuse_dt)
         else:
+            fuse_dt = False
             with torch.cuda.device(dev), _lib.timed("conv1d_fwd", dev):
                 rc = lib.simamba_causal_conv1d_fwd(x_in.data_ptr(), cw.data_ptr(), _lib.ptr(cb), x_conv.data_ptr(),
                                                    Bsz, Dm, L, W, 1, code, xbs, stream)
@@ -160,17 +172,25 @@ class MambaInnerFn(torch.autograd.Function):
                 x_dbl = _xw(x_conv.transpose(1, 2), xw_c.t())                          # (B, L, S)
                 delta = _wx(dtw_c, x_dbl[:, :, :R].transpose(1, 2))                    # (B, D, L)
         Bv, Cv = x_dbl[:, :, R:R + N], x_dbl[:, :, R + N:]                            # (B, L, N) views
+        if x_dbl.data_ptr() % 16:
+            raise RuntimeError("mamba_inner_fn: unaligned x_proj output")              # the allocator never does this
 
-        need_grad = any(ctx.needs_input_grad)
-        aligned = xz.data_ptr() % 16 == 0 and (xbs * xz.element_size()) % 16 == 0 and x_dbl.data_ptr() % 16 == 0
-        ckpt_step, x_ckpt = _lib.scan_plan(Bsz, Dm, L, N, io, aligned, dev, need_grad)
         y = torch.empty(Bsz, Dm, L, device=dev, dtype=io)
+        dtw_k = dtw_c.contiguous() if fuse_dt else None
         with torch.cuda.device(dev), _lib.timed("scan_fwd", dev):
-            rc = lib.simamba_selective_scan_fwd(
-                x_conv.data_ptr(), delta.data_ptr(), Af.data_ptr(), Bv.data_ptr(), Cv.data_ptr(), _lib.ptr(Df),
-                z.data_ptr(), _lib.ptr(bf), y.data_ptr(), _lib.ptr(x_ckpt), None,
-                Bsz, Dm, L, N, code, 1, xbs, x_dbl.stride(0), 1, x_dbl.stride(1),
-                ckpt_step, _lib.current_scan_variant(), stream)
+            if fuse_dt:
+                _lib.count("scan_dt_fwd")
+                rc = lib.simamba_selective_scan_dt_fwd(
+                    x_conv.data_ptr(), x_dbl.data_ptr(), dtw_k.data_ptr(), Af.data_ptr(), _lib.ptr(Df),
+                    z.data_ptr(), _lib.ptr(bf), y.data_ptr(), _lib.ptr(x_ckpt), None,
+                    Bsz, Dm, L, N, R, code, xbs, x_dbl.stride(0), x_dbl.stride(1),
+                    ckpt_step, _lib.current_scan_variant(), stream)
+            else:
+                rc = lib.simamba_selective_scan_fwd(
+                    x_conv.data_ptr(), delta.data_ptr(), Af.data_ptr(), Bv.data_ptr(), Cv.data_ptr(), _lib.ptr(Df),
+                    z.data_ptr(), _lib.ptr(bf), y.data_ptr(), _lib.ptr(x_ckpt), None,
+                    Bsz, Dm, L, N, code, 1, xbs, x_dbl.stride(0), 1, x_dbl.stride(1),
+                    ckpt_step, _lib.current_scan_variant(), stream)
         _lib.check(rc, "simamba_selective_scan_fwd")
 
         out = _xw(y.transpose(1, 2), ow_c.t())                                         # (B, L, d)
@@ -178,6 +198,7 @@ class MambaInnerFn(torch.autograd.Function):
             out = out + _w(out_proj_b, io)
         ctx.dims = (R, N, W)
         ctx.ckpt_step = ckpt_step
+        ctx.dtw_k = dtw_k                                   # not None: delta was formed inside the scan (no tensor)
         ctx.has_out_bias = out_proj_b is not None
         ctx.param_dtypes = (conv_w.dtype, None if conv_b is None else conv_b.dtype, x_proj_w.dtype,
                             dt_proj_w.dtype, out_proj_w.dtype, A.dtype,
@@ -220,12 +241,20 @@ class MambaInnerFn(torch.autograd.Function):
         Bv, Cv = x_dbl[:, :, R:R + N], x_dbl[:, :, R + N:]
         z, dz = xz[:, Dm:], dxz[:, Dm:]
         with torch.cuda.device(dev), _lib.timed("scan_bwd", dev):
-            rc = lib.simamba_selective_scan_bwd(
-                x_conv.data_ptr(), delta.data_ptr(), Af.data_ptr(), Bv.data_ptr(), Cv.data_ptr(), _lib.ptr(Df),
-                z.data_ptr(), _lib.ptr(bf), dy.data_ptr(), _lib.ptr(x_ckpt),
-                du.data_ptr(), ddelta.data_ptr(), dA.data_ptr(), dB.data_ptr(), dC.data_ptr(), _lib.ptr(dD),
-                dz.data_ptr(), _lib.ptr(dbias), Bsz, Dm, L, N, code, 1,
-                xbs, dxz.stride(0), x_dbl.stride(0), 1, x_dbl.stride(1), ctx.ckpt_step, stream)
+            if ctx.dtw_k is not None:
+                rc = lib.simamba_selective_scan_dt_bwd(
+                    x_conv.data_ptr(), x_dbl.data_ptr(), ctx.dtw_k.data_ptr(), Af.data_ptr(), _lib.ptr(Df),
+                    z.data_ptr(), _lib.ptr(bf), dy.data_ptr(), _lib.ptr(x_ckpt),
+                    du.data_ptr(), ddelta.data_ptr(), dA.data_ptr(), dB.data_ptr(), dC.data_ptr(), _lib.ptr(dD),
+                    dz.data_ptr(), _lib.ptr(dbias), Bsz, Dm, L, N, R, code,
+                    xbs, dxz.stride(0), x_dbl.stride(0), x_dbl.stride(1), stream)
+            else:
+                rc = lib.simamba_selective_scan_bwd(
+                    x_conv.data_ptr(), delta.data_ptr(), Af.data_ptr(), Bv.data_ptr(), Cv.data_ptr(), _lib.ptr(Df),
+                    z.data_ptr(), _lib.ptr(bf), dy.data_ptr(), _lib.ptr(x_ckpt),
+                    du.data_ptr(), ddelta.data_ptr(), dA.data_ptr(), dB.data_ptr(), dC.data_ptr(), _lib.ptr(dD),
+                    dz.data_ptr(), _lib.ptr(dbias), Bsz, Dm, L, N, code, 1,
+                    xbs, dxz.stride(0), x_dbl.stride(0), 1, x_dbl.stride(1), ctx.ckpt_step, stream)
         _lib.check(rc, "simamba_selective_scan_bwd")
 
         # dt_proj / x_proj
