@@ -340,11 +340,15 @@ __device__ __forceinline__ void seq_body(const SeqArgs& p, const int b, const in
     // LDS reads run one step (B_t | C_t) ahead of their use; the sched_barriers keep hipcc from sinking them
     // back next to the consumer (it did, exposing ~200 cycles of LDS latency per step)
     const int q3 = lane_v & 3;
+    // float offset of column group g of this lane's row: rowB * 32 + 4 (g ^ s) = (rowB * 32 + 4 s) ^ (4 g) -- the XOR
+    // only touches the three bits below the row's stride
+    const int rowBv = lane_v / kLPC;
+    const int tbase = rowBv * kSeqTC + 4 * ((rowBv >> 1) & 7);
     float4 b4n = *reinterpret_cast<const float4*>(tBC + 4 * q3);
     float4 c4n = *reinterpret_cast<const float4*>(tBC + 16 + 4 * q3);
 #pragma unroll 1
     for (int g = 0; g < kSeqTC / 4; ++g) {
-      const int o = tile_off(rowB, g);
+      const int o = tbase ^ (4 * g);
       const float4 d4 = *reinterpret_cast<const float4*>(tD + o);
       const float4 u4 = *reinterpret_cast<const float4*>(tU + o);
       const float dl[4] = {d4.x, d4.y, d4.z, d4.w};
@@ -388,8 +392,13 @@ __device__ __forceinline__ void seq_body(const SeqArgs& p, const int b, const in
           }
         }
         float y = ys[0] + ys[1];
-        y += dpp<DPP_QUAD_XOR1>(0.f, y);
-        if (kLPC == 4) y += dpp<DPP_QUAD_XOR2>(0.f, y);
+        // the kLPC partial sums of a channel, one fused DPP add per stage (hipcc makes v_mov_b32_dpp + v_add_f32 of the
+        // update_dpp builtin); s_nop: "VALU write -> DPP read: 2 wait states", not padded inside asm
+        if (kLPC == 4)
+          asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+              "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "+v"(y));
+        else
+          asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(y));
         yy[i] = y;
         __builtin_amdgcn_sched_barrier(0);
       }

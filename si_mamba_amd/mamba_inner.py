@@ -120,7 +120,7 @@ def xdt_proj_fwd(x, wx, wdt, conv=None, want_delta=True):
 class MambaInnerFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, xz, conv_w, conv_b, x_proj_w, dt_proj_w, out_proj_w, out_proj_b, A, D, delta_bias,
-                dt_rank, d_state):
+                dt_rank, d_state, grad_mode=True):
         _lib.require_gpu(xz, "mamba_inner_fn")
         lib = _lib.load()
         if xz.stride(2) != 1 or xz.stride(1) != xz.shape[2]:
@@ -146,7 +146,8 @@ class MambaInnerFn(torch.autograd.Function):
         xw_c, dtw_c, ow_c = _w(x_proj_w, io), _w(dt_proj_w, io), _w(out_proj_w, io)   # compute-dtype weights,
         ctx.wcast = (xw_c, dtw_c, ow_c)                                               # reused by backward
         x_conv = torch.empty(Bsz, Dm, L, device=dev, dtype=io)
-        need_grad = any(ctx.needs_input_grad)
+        # (ctx.needs_input_grad is True under torch.no_grad() too: the caller's grad mode comes in as an argument)
+        need_grad = grad_mode and any(ctx.needs_input_grad)
         pack = 4 if io == torch.float32 else 8
         aligned = xz.data_ptr() % 16 == 0 and (xbs * xz.element_size()) % 16 == 0
         ckpt_step, x_ckpt = _lib.scan_plan(Bsz, Dm, L, N, io, aligned, dev, need_grad)
@@ -284,7 +285,7 @@ class MambaInnerFn(torch.autograd.Function):
         t_cw, t_cb, t_xw, t_dtw, t_ow, t_A, t_D, t_b = ctx.param_dtypes
         return (dxz, dcw.to(t_cw), None if dcb is None else dcb.to(t_cb), d_x_w.to(t_xw), d_dt_w.to(t_dtw),
                 d_out_w.to(t_ow), None if d_out_b is None else d_out_b.to(out_proj_w.dtype), dA.to(t_A),
-                None if dD is None else dD.to(t_D), None if dbias is None else dbias.to(t_b), None, None)
+                None if dD is None else dD.to(t_D), None if dbias is None else dbias.to(t_b), None, None, None)
 
 
 def mamba_inner_fn(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight,
@@ -301,4 +302,4 @@ def mamba_inner_fn(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_wei
     if d_state is None:
         d_state = (x_proj_weight.shape[0] - dt_rank) // 2
     return MambaInnerFn.apply(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight,
-                              out_proj_bias, A, D, delta_bias, dt_rank, d_state)
+                              out_proj_bias, A, D, delta_bias, dt_rank, d_state, torch.is_grad_enabled())

@@ -30,7 +30,7 @@ def _bc_bnl(M, name):
 class SelectiveScanFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, u, delta, A, B, C, D=None, z=None, delta_bias=None,
-                delta_softplus=False, return_last_state=False):
+                delta_softplus=False, return_last_state=False, grad_mode=True):
         _lib.require_gpu(u, "selective_scan_fn")
         lib = _lib.load()
         io = u.dtype
@@ -56,7 +56,8 @@ class SelectiveScanFn(torch.autograd.Function):
             zc = zc.contiguous()
         bc = None if delta_bias is None else delta_bias.float().contiguous()
         out = torch.empty_like(uc)
-        needs_grad = any(t is not None and t.requires_grad for t in (u, delta, A, B, C, D, z, delta_bias))
+        # ctx.needs_input_grad is True under torch.no_grad() too: the caller's grad mode comes in as an argument
+        needs_grad = grad_mode and any(ctx.needs_input_grad)
         aligned = all(t is None or t.data_ptr() % 16 == 0 for t in (uc, dc, Bc, Cc, zc))
         ckpt_step, x_ckpt = _lib.scan_plan(batch, dim, L, N, io, aligned and bool(delta_softplus), u.device, needs_grad)
         last = (torch.empty(batch, dim, N, device=u.device, dtype=torch.float32)
@@ -115,7 +116,7 @@ class SelectiveScanFn(torch.autograd.Function):
                 None if dD is None else dD.to(dt_D),
                 None if dz is None else dz.to(dt_z),
                 None if dbias is None else dbias.to(dt_bias),
-                None, None)
+                None, None, None)
 
 
 def selective_scan_fn(u, delta, A, B, C, D=None, z=None, delta_bias=None,
@@ -124,4 +125,5 @@ def selective_scan_fn(u, delta, A, B, C, D=None, z=None, delta_bias=None,
 
     Returns out (B, D, L) in u's dtype, plus last_state (B, D, N) fp32 when asked.
     """
-    return SelectiveScanFn.apply(u, delta, A, B, C, D, z, delta_bias, delta_softplus, return_last_state)
+    return SelectiveScanFn.apply(u, delta, A, B, C, D, z, delta_bias, delta_softplus, return_last_state,
+                                 torch.is_grad_enabled())
