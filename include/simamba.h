@@ -15,6 +15,8 @@
  *   simamba_xdt_proj_fwd             the x_proj / dt_proj GEMM pair of the same mixer (cuBLAS calls inside
  *                                    upstream's mamba_inner_fn).
  *   simamba_add_layer_norm_fwd/bwd   the Add -> LayerNorm of models/block.py:56-60 (torch ops there).
+ *   simamba_out_proj_add_ln_fwd      out_proj of the mixer + that Add -> LayerNorm, one kernel (bf16).
+ *   simamba_selective_scan_dt_fwd/bwd  the scan with delta formed in the kernel (same call site, bf16 path).
  *   simamba_knn_graph                models/point_mamba.py:620-661 and :664-715
  *                                    (create_graph_from_centers / ..._feature_space_...).
  *   simamba_laplacian_topk           models/point_mamba.py:717-761 and :764-814
@@ -255,6 +257,21 @@ int simamba_add_layer_norm_bwd(const void* dnormed, const float* dresidual_out,
                                const float* weight, const float* rowscale, float* dresidual,
                                void* dhidden, float* dwb_partial, int batch, int rows_per_batch,
                                int dim, int hidden_dtype, int out_dtype, void* stream);
+
+/*
+ * out_proj -> (+ DropPath-scaled residual) -> LayerNorm in one kernel on the matrix cores, bf16 operands: the mixer's
+ * out_proj (upstream mamba_inner_fn, models/block.py:72) fused with the Add -> LayerNorm that opens the next block
+ * (models/block.py:56-58) or closes the stack (models/point_mamba.py:257-258).  The out_proj result is rounded to bf16
+ * (the rounding the reference's autocast GEMM output has) and never written:
+ *   y : (batch, K, L) bf16, L contiguous ; w : (C, K) bf16 ; residual : (batch, L, C) fp32 or NULL ;
+ *   rowscale : (batch) fp32 or NULL (applied to the out_proj result when residual != NULL) ; gamma, beta : (C) fp32 ;
+ *   residual_out : (batch, L, C) fp32 = bf16(y^T w^T) * rowscale + residual ; normed : out_dtype = LayerNorm(residual_out) ;
+ *   mean, rstd : (batch * L) fp32 for simamba_add_layer_norm_bwd.
+ * C % 128 == 0, C <= 384, K % 64 == 0, L % 8 == 0, K * L * 2 < 2^32, 16-byte aligned pointers.
+ */
+int simamba_out_proj_add_ln_fwd(const void* y, const void* w, const float* residual, const float* rowscale,
+                                const float* gamma, const float* beta, float* residual_out, void* normed, float* mean,
+                                float* rstd, int batch, int K, int L, int C, float eps, int out_dtype, void* stream);
 
 /*
  * Patch-encoder streaming ops (reference models/point_mamba.py:46-73, Encoder: Conv1d - BatchNorm1d - ReLU -

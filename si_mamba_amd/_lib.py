@@ -65,6 +65,8 @@ SIGNATURES = {
                                            c_int, c_int, _P]),
     "simamba_add_layer_norm_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int,
                                            c_int, c_int, _P]),
+    "simamba_out_proj_add_ln_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float,
+                                            c_int, _P]),
     "simamba_bn_relu_grid": (c_int, [_LL]),
     "simamba_bn_relu_fwd": (c_int, [_P, _P, c_int, _P, _P, _P, _P, c_float, c_float, c_int, _P, _P, _P, _P, _LL, c_int,
                                     _LL, c_int, _P]),

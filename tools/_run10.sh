@@ -1,0 +1,4 @@
+set -u
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+timeout -k 10 600 python -m pytest tests/test_gpu_out_norm.py -m gpu -q --no-header -rf -p no:cacheprovider -x > gpurun_out/tests_on.log 2>&1; rc=$?
+tail -25 gpurun_out/tests_on.log | cut -c1-200

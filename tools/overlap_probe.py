@@ -1,12 +1,15 @@
 """Do a VALU-bound scan kernel and an MFMA-bound library GEMM overlap when issued on two HIP streams?  (diagnostic)
 
-Backward of one mixer at the bench shape: scan bwd (VALU-bound, 2 waves/SIMD at 241 VGPRs) next to the two weight-gradient
+Backward of one mixer at the bench shape: scan bwd (VALU-bound; the sequential kernel holds 3 waves/SIMD at <= 168 VGPRs and
+53 KB of LDS per workgroup, SIMAMBA_CKPT=128 selects the row-scan one: 2 waves at 241) next to the two weight-gradient
 GEMMs that are off the critical path (out_proj wgrad, in_proj wgrad; fp32 MFMA at ~140 TF/s).  Prints the time of the two
 run back to back on one stream and of the same work issued on two streams."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from si_mamba_amd import _lib
+if os.environ.get("SIMAMBA_LIB"):                                  # an A/B build from tools/build_alt.sh
+    _lib.LIB_PATH = os.path.abspath(os.environ["SIMAMBA_LIB"])
 from si_mamba_amd.gemm_tuning import enable_tuned_gemms
 from si_mamba_amd.synthetic import scan_inputs
 
