@@ -270,6 +270,29 @@ def fuse_dt_enabled(dtype):
     return (dtype == torch.bfloat16) if _fuse_dt[0] is None else _fuse_dt[0]
 
 
+_fuse_out_norm = [True]
+
+
+class fuse_out_norm:
+    """Context manager for benchmarks and parity tests: let MixerModel.forward apply out_proj fused with the next block's
+    add + LayerNorm (out_norm.py; the default wherever the kernel's shapes apply) or op by op as the reference does."""
+
+    def __init__(self, on):
+        self.v, self.prev = bool(on), None
+
+    def __enter__(self):
+        self.prev, _fuse_out_norm[0] = _fuse_out_norm[0], self.v
+        return self
+
+    def __exit__(self, *exc):
+        _fuse_out_norm[0] = self.prev
+        return False
+
+
+def fuse_out_norm_enabled():
+    return _fuse_out_norm[0]
+
+
 def scan_plan(batch, dim, seqlen, dstate, dtype, aligned, device, need_grad):
     """(ckpt_step, x_ckpt or None) for one forward / backward pair.  ``aligned``: the caller's statement that every
     activation operand is 16-byte aligned with pack-aligned strides (what the sequential backward needs; the library

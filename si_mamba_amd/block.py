@@ -20,8 +20,10 @@ import torch
 import torch.nn as nn
 from torch import Tensor
 
+from . import _lib
 from .add_norm import add_layer_norm_fn
 from .mamba_simple import Mamba
+from .out_norm import out_proj_add_ln_fn, out_proj_add_ln_ok
 
 
 class DropPath(nn.Module):
@@ -140,10 +142,11 @@ class MixerModel(nn.Module):
         return {i: layer.allocate_inference_cache(batch_size, max_seqlen, dtype=dtype, **kwargs)
                 for i, layer in enumerate(self.layers)}
 
-    def _first_block_on_distinct_tokens(self, tokens, pos, token_index, A=None):
+    def _first_block_on_distinct_tokens(self, tokens, pos, token_index, A=None, emit_y=False):
         """Block 0 when the sequence is ``gather(tokens + pos, token_index)``: Add + LayerNorm + in_proj on the G
         distinct tokens, expanded to the L positions by a copy kernel (seq_expand.py).  -> (hidden, residual) of
-        block 0 as the reference's Block.forward returns them, or None when the route does not apply."""
+        block 0 as the reference's Block.forward returns them (``emit_y``: the mixer's output before out_proj in
+        place of hidden, see _chain), or None when the route does not apply."""
         from . import seq_expand
         layer = self.layers[0]
         mixer = layer.mixer
@@ -161,7 +164,7 @@ class MixerModel(nn.Module):
         else:
             normed, res0 = add_layer_norm_fn(tokens + pos, None, layer.norm.weight, layer.norm.bias, layer.norm.eps)
         xz = seq_expand.seq_gather_last(mixer.in_proj_xz(normed), idx32, inv32)          # (B, 2D, L)
-        hidden = mixer.forward_xz(xz, A=A)
+        hidden = mixer.forward_xz(xz, A=A, emit_y=emit_y)
         residual = torch.gather(res0, 1, token_index.unsqueeze(-1).expand(-1, -1, res0.shape[-1]))
         return hidden, residual
 
@@ -175,6 +178,57 @@ class MixerModel(nn.Module):
             return list((-torch.exp(torch.stack([m.A_log for m in mixers]).float())).unbind(0))
         return [None] * len(mixers)
 
+    def _chain_ok(self, x):
+        """Can the stack run as  add+LN -> [in_proj -> mixer body -> (out_proj + add + LN)] * n  with the bracketed
+        out_proj / add / LayerNorm as ONE kernel (out_norm.py)?  bf16 compute (autocast or bf16 modules), plain
+        LayerNorm blocks around fast-path Mamba mixers without an out_proj bias, nothing between the blocks."""
+        if not (_lib.fuse_out_norm_enabled() and x.is_cuda and x.dim() == 3
+                and isinstance(self.drop_out_in_block, nn.Identity) and type(self.norm_f) is nn.LayerNorm):
+            return False
+        io = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else x.dtype
+        if io != torch.bfloat16:
+            return False
+        d_model = x.shape[-1]
+        for layer in self.layers:
+            m = layer.mixer
+            if not (type(layer) is Block and type(layer.norm) is nn.LayerNorm and type(m) is Mamba and m.use_fast_path
+                    and m.out_proj.bias is None and m.d_model == d_model and d_model % 128 == 0 and d_model <= 384
+                    and m.d_inner % 64 == 0):
+                return False
+        return True
+
+    def _chain(self, first, y, normed, residual, A_all):
+        """Blocks ``first``.. of the stack and its final norm on the fused route.  Enters either with ``normed`` (the
+        LayerNorm output block ``first`` feeds its mixer) or with ``y`` (block ``first - 1``'s mixer output before
+        out_proj); ``residual`` is the fp32 residual stream that goes with it.  What the reference computes across each
+        block boundary -- out_proj (models/block.py:72), residual = drop_path(hidden) + residual and norm(residual) at
+        the top of the next block (:56-58), or norm_f after the last (models/point_mamba.py:257-258) -- is one kernel;
+        shapes it does not take run the same three ops through the library GEMM and the add + LayerNorm kernel."""
+        n = len(self.layers)
+        i = first
+        while True:
+            if y is not None:                               # close block i - 1, open block i (or finish the stack)
+                prev = self.layers[i - 1].mixer
+                if i < n:
+                    norm, dp = self.layers[i].norm, self.layers[i].drop_path
+                    scale = dp.rowscale(y) if isinstance(dp, DropPath) else None
+                    out_dtype = torch.bfloat16
+                else:
+                    norm, scale, out_dtype = self.norm_f, None, self.norm_f.weight.dtype
+                if out_proj_add_ln_ok(y, prev.out_proj.weight, prev.d_model):
+                    _lib.count("out_proj_add_ln")
+                    normed, residual = out_proj_add_ln_fn(y, prev.out_proj.weight, residual, norm.weight, norm.bias,
+                                                          norm.eps, rowscale=scale, out_dtype=out_dtype)
+                else:
+                    hidden = torch.matmul(y.transpose(1, 2), prev.out_proj.weight.t().to(y.dtype))
+                    normed, residual = add_layer_norm_fn(hidden, residual, norm.weight, norm.bias, norm.eps,
+                                                         rowscale=scale, out_dtype=out_dtype)
+                if i == n:
+                    return normed
+            mixer = self.layers[i].mixer
+            y = mixer.forward_xz(mixer.in_proj_xz(normed), A=A_all[i], emit_y=True)
+            i += 1
+
     def forward(self, input_ids, pos, inference_params=None, token_index=None, balanced_index=False):
         """Reference signature (models/point_mamba.py:247).  ``token_index`` (B, L) int64, optional and specific to
         this implementation: when given, ``input_ids`` / ``pos`` are the G DISTINCT tokens (B, G, C) and the sequence
@@ -186,11 +240,14 @@ class MixerModel(nn.Module):
         first = 0
         residual = None
         A_all = self._precompute_A()
+        chain = inference_params is None and len(self.layers) > 0 and self._chain_ok(input_ids)
         if token_index is not None:
-            done = (self._first_block_on_distinct_tokens(input_ids, pos, token_index, A=A_all[0])
+            done = (self._first_block_on_distinct_tokens(input_ids, pos, token_index, A=A_all[0], emit_y=chain)
                     if (balanced_index and inference_params is None) else None)
             if done is not None:
                 hidden_states, residual = done
+                if chain:                                   # hidden_states is block 0's y (B, d_inner, L)
+                    return self._chain(1, hidden_states, None, residual, A_all)
                 hidden_states = self.drop_out_in_block(hidden_states)
                 first = 1
             else:                                       # the reference's route on the expanded sequence
@@ -199,6 +256,12 @@ class MixerModel(nn.Module):
                 pos = torch.gather(pos, 1, ex.expand(-1, -1, pos.shape[-1]))
         if first == 0:
             hidden_states = input_ids + pos
+        if chain:
+            l0 = self.layers[0]
+            scale = l0.drop_path.rowscale(hidden_states) if isinstance(l0.drop_path, DropPath) else None
+            normed, residual = add_layer_norm_fn(hidden_states, None, l0.norm.weight, l0.norm.bias, l0.norm.eps,
+                                                 rowscale=scale)
+            return self._chain(0, None, normed, residual, A_all)
         for i in range(first, len(self.layers)):
             hidden_states, residual = self.layers[i](hidden_states, residual, inference_params=inference_params,
                                                      A=A_all[i])

@@ -180,7 +180,10 @@ __global__ __launch_bounds__(kOnThreads, 2) void out_proj_add_ln_kernel(OnArgs p
   load_w(wa, 0);
   load_y(yb, 1);
   store_y(ya, 0);
-  for (int ks = 0; ks < nk; ks += 2) {
+#ifndef ON_NK
+#define ON_NK nk
+#endif
+  for (int ks = 0; ks < ON_NK; ks += 2) {
     __syncthreads();
     store_y(yb, 1);
     load_w(wb, ks + 1); load_y(ya, ks + 2);
@@ -240,8 +243,11 @@ __global__ __launch_bounds__(kOnThreads, 2) void out_proj_add_ln_kernel(OnArgs p
   const float scale = (p.rowscale && p.residual) ? p.rowscale[b] : 1.f;
   const float inv_dim = 1.f / C;
   TO* __restrict__ og = static_cast<TO*>(p.normed);
+#ifndef ON_ROWS
+#define ON_ROWS kRows
+#endif
 #pragma unroll
-  for (int r = 0; r < kRows; ++r) {
+  for (int r = 0; r < ON_ROWS; ++r) {
     const int tl = kRows * wave + r;
     if (t0 + tl < L) {                                         // wave-uniform
       const size_t row = static_cast<size_t>(b) * L + t0 + tl;

@@ -143,7 +143,11 @@ class MambaInnerFn(torch.autograd.Function):
         bf = None if delta_bias is None else delta_bias.float().contiguous()
         W = cw.shape[1]
 
-        xw_c, dtw_c, ow_c = _w(x_proj_w, io), _w(dt_proj_w, io), _w(out_proj_w, io)   # compute-dtype weights,
+        # out_proj_w None: the caller applies out_proj itself (out_norm.py fuses it with the next block's add +
+        # LayerNorm) and this node returns the gated scan output y (B, D, L)
+        no_out = out_proj_w is None
+        xw_c, dtw_c = _w(x_proj_w, io), _w(dt_proj_w, io)                             # compute-dtype weights,
+        ow_c = None if no_out else _w(out_proj_w, io)
         ctx.wcast = (xw_c, dtw_c, ow_c)                                               # reused by backward
         x_conv = torch.empty(Bsz, Dm, L, device=dev, dtype=io)
         # (ctx.needs_input_grad is True under torch.no_grad() too: the caller's grad mode comes in as an argument)
@@ -194,18 +198,22 @@ class MambaInnerFn(torch.autograd.Function):
                     ckpt_step, _lib.current_scan_variant(), stream)
         _lib.check(rc, "simamba_selective_scan_fwd")
 
-        out = _xw(y.transpose(1, 2), ow_c.t())                                         # (B, L, d)
-        if out_proj_b is not None:
-            out = out + _w(out_proj_b, io)
+        if no_out:
+            out = y
+        else:
+            out = _xw(y.transpose(1, 2), ow_c.t())                                     # (B, L, d)
+            if out_proj_b is not None:
+                out = out + _w(out_proj_b, io)
+        ctx.no_out = no_out
         ctx.dims = (R, N, W)
         ctx.ckpt_step = ckpt_step
         ctx.dtw_k = dtw_k                                   # not None: delta was formed inside the scan (no tensor)
-        ctx.has_out_bias = out_proj_b is not None
+        ctx.has_out_bias = out_proj_b is not None and not no_out
         ctx.param_dtypes = (conv_w.dtype, None if conv_b is None else conv_b.dtype, x_proj_w.dtype,
-                            dt_proj_w.dtype, out_proj_w.dtype, A.dtype,
+                            dt_proj_w.dtype, None if no_out else out_proj_w.dtype, A.dtype,
                             None if D is None else D.dtype, None if delta_bias is None else delta_bias.dtype)
-        ctx.save_for_backward(xz, x_conv, x_dbl, delta, y, cw, cb, x_proj_w, dt_proj_w, out_proj_w, Af, Df, bf,
-                              x_ckpt)
+        ctx.save_for_backward(xz, x_conv, x_dbl, delta, None if no_out else y, cw, cb, x_proj_w, dt_proj_w, out_proj_w,
+                              Af, Df, bf, x_ckpt)
         return out
 
     @staticmethod
@@ -222,15 +230,18 @@ class MambaInnerFn(torch.autograd.Function):
         stream = _lib.stream_ptr(dev)
         xbs = xz.stride(0)
         dout = dout.to(io)
-        if dout.stride(2) != 1:
-            dout = dout.contiguous()
         f32 = dict(device=dev, dtype=torch.float32)
-
-        # out_proj
-        d_out_w = _sum_bmm(dout.transpose(1, 2), y.transpose(1, 2))                   # (d, D)
-        d_out_b = dout.sum((0, 1)) if ctx.has_out_bias else None
         xw_c, dtw_c, ow_c = ctx.wcast
-        dy = _wx(ow_c.t(), dout.transpose(1, 2))                                      # (B, D, L)
+        if ctx.no_out:                                                                # the gradient IS dy (B, D, L)
+            dy = dout.contiguous()
+            d_out_w = d_out_b = None
+        else:
+            if dout.stride(2) != 1:
+                dout = dout.contiguous()
+            # out_proj
+            d_out_w = _sum_bmm(dout.transpose(1, 2), y.transpose(1, 2))               # (d, D)
+            d_out_b = dout.sum((0, 1)) if ctx.has_out_bias else None
+            dy = _wx(ow_c.t(), dout.transpose(1, 2))                                  # (B, D, L)
 
         # selective scan
         dxz = torch.empty_like(xz)
@@ -284,13 +295,15 @@ class MambaInnerFn(torch.autograd.Function):
 
         t_cw, t_cb, t_xw, t_dtw, t_ow, t_A, t_D, t_b = ctx.param_dtypes
         return (dxz, dcw.to(t_cw), None if dcb is None else dcb.to(t_cb), d_x_w.to(t_xw), d_dt_w.to(t_dtw),
-                d_out_w.to(t_ow), None if d_out_b is None else d_out_b.to(out_proj_w.dtype), dA.to(t_A),
+                None if d_out_w is None else d_out_w.to(t_ow),
+                None if d_out_b is None else d_out_b.to(out_proj_w.dtype), dA.to(t_A),
                 None if dD is None else dD.to(t_D), None if dbias is None else dbias.to(t_b), None, None, None)
 
 
 def mamba_inner_fn(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight,
                    out_proj_bias, A, D=None, delta_bias=None, dt_rank=None, d_state=None):
-    """xz: (B, 2D, L); conv1d_weight: (D, W) or (D, 1, W); returns (B, L, d_model).
+    """xz: (B, 2D, L); conv1d_weight: (D, W) or (D, 1, W); returns (B, L, d_model) -- or, with ``out_proj_weight=None``
+    (beyond upstream's signature), the gated scan output y (B, D, L) that out_proj would be applied to.
 
     ``B``/``C`` are always input-dependent (taken from x_proj), delta_softplus is always on: the only
     configuration the reference's mixer uses.

@@ -110,15 +110,17 @@ class Mamba(nn.Module):
         """(B, L, d_model) -> xz (B, 2 d_inner, L), L contiguous: the in_proj half of forward()."""
         return in_proj_fn(hidden_states, self.in_proj.weight, self.in_proj.bias)
 
-    def forward_xz(self, xz, A=None):
+    def forward_xz(self, xz, A=None, emit_y=False):
         """xz (B, 2 d_inner, L) -> (B, L, d_model): everything after in_proj as one autograd node, no
         activation-sized copies (mamba_inner.py).  forward(h) == forward_xz(in_proj_xz(h)); MixerModel calls the two
         halves separately for the first block when the sequence is an expansion of fewer distinct tokens
-        (seq_expand.py)."""
+        (seq_expand.py).  ``emit_y=True``: stop before out_proj and return the gated scan output (B, d_inner, L) --
+        MixerModel then applies out_proj fused with the next block's add + LayerNorm (out_norm.py)."""
         if A is None:                                       # MixerModel hands over -exp(A_log) of all its layers at once
             A = -torch.exp(self.A_log.float())
         return mamba_inner_fn(xz, self.conv1d.weight, self.conv1d.bias, self.x_proj.weight,
-                              self.dt_proj.weight, self.out_proj.weight, self.out_proj.bias, A,
+                              self.dt_proj.weight, None if emit_y else self.out_proj.weight,
+                              None if emit_y else self.out_proj.bias, A,
                               self.D.float(), delta_bias=self.dt_proj.bias.float(),
                               dt_rank=self.dt_rank, d_state=self.d_state)
 

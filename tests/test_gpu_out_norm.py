@@ -85,3 +85,47 @@ def test_out_proj_add_ln_matches_unfused_route_and_backward(B, C, L, device):
     names = ("normed", "res_out", "dy", "dw", "dres", "dgamma", "dbeta")
     for n, a, b_ in zip(names, outs[True], outs[False]):
         assert nerr(a, b_) < 1e-2, n
+
+
+@pytest.mark.parametrize("mode", ["expanded", "plain"])
+@pytest.mark.parametrize("train", [True, False])
+def test_mixer_model_fused_boundaries_match_op_by_op_route(mode, train, device):
+    """MixerModel.forward under bf16 autocast: every block boundary (out_proj, DropPath-scaled add, LayerNorm --
+    models/block.py:72, :56-58; the stack's norm_f, models/point_mamba.py:257-258) through the fused kernel against the
+    same stack op by op (library out_proj GEMM + add_layer_norm kernel).  Same seed, so the same DropPath draws.
+    Output, input gradients and every parameter gradient at bf16 tolerance; the counter shows the route was taken."""
+    from si_mamba_amd import _lib
+    from si_mamba_amd.block import MixerModel
+    torch.manual_seed(3)
+    B, G, d, n = 3, 32, 128, 3
+    model = MixerModel(d, n, ssm_cfg={}, drop_path=0.2 if train else 0.0).to(device).train(train)
+    g = torch.Generator().manual_seed(11)
+    tok = torch.randn(B, G, d, generator=g).to(device)
+    pos = torch.randn(B, G, d, generator=g).to(device)
+    if mode == "expanded":
+        idx = torch.stack([torch.cat([torch.randperm(G, generator=g) for _ in range(4)]) for _ in range(B)]).to(device)
+        kw = dict(token_index=idx, balanced_index=True)
+        dout = torch.randn(B, 4 * G, d, generator=g).to(device)
+    else:
+        kw = {}
+        dout = torch.randn(B, G, d, generator=g).to(device)
+    res = {}
+    for fused in (True, False):
+        model.zero_grad(set_to_none=True)
+        t, p = tok.clone().requires_grad_(True), pos.clone().requires_grad_(True)
+        _lib.counters.pop("out_proj_add_ln", None)
+        torch.manual_seed(5)
+        with _lib.fuse_out_norm(fused), torch.autocast("cuda", dtype=torch.bfloat16):
+            out = model(t, p, **kw)
+        assert _lib.counters.get("out_proj_add_ln", 0) == (n if fused else 0)
+        assert out.dtype == torch.float32
+        (out * dout).sum().backward()
+        res[fused] = (out.detach(), t.grad, p.grad, {k: v.grad for k, v in model.named_parameters()})
+    assert nerr(res[True][0], res[False][0]) < 2e-2
+    assert nerr(res[True][1], res[False][1]) < 3e-2
+    assert nerr(res[True][2], res[False][2]) < 3e-2
+    for k, ga in res[True][3].items():
+        gb = res[False][3][k]
+        assert (ga is None) == (gb is None), k
+        if ga is not None:
+            assert nerr(ga, gb) < 4e-2, k
