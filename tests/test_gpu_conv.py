@@ -31,7 +31,8 @@ def test_conv_golden(name, device):
 
 
 @pytest.mark.parametrize("shape", [(2, 256, 64, 4), (3, 100, 128, 4), (2, 24, 1024, 4), (2, 33, 50, 3),
-                                   (1, 7, 1, 2), (1, 16, 2100, 4), (64, 768, 128, 4)])
+                                   (1, 7, 1, 2), (1, 16, 2100, 4), (64, 768, 128, 4),
+                                   (1, 16, 4096, 4), (2, 8, 8, 4), (3, 40, 16, 3)])   # aligned rows: the pipelined backward
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("act", [None, "silu"])
 def test_conv_random(shape, dtype, act, device):
