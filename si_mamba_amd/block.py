@@ -185,7 +185,9 @@ class MixerModel(nn.Module):
         if not (_lib.fuse_out_norm_enabled() and x.is_cuda and x.dim() == 3
                 and isinstance(self.drop_out_in_block, nn.Identity) and type(self.norm_f) is nn.LayerNorm):
             return False
-        io = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else x.dtype
+        # the dtype the projections compute in: autocast's, else the parameters'
+        io = (torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda")
+              else self.layers[0].mixer.in_proj.weight.dtype)
         if io != torch.bfloat16:
             return False
         d_model = x.shape[-1]
@@ -212,7 +214,7 @@ class MixerModel(nn.Module):
                 if i < n:
                     norm, dp = self.layers[i].norm, self.layers[i].drop_path
                     scale = dp.rowscale(y) if isinstance(dp, DropPath) else None
-                    out_dtype = torch.bfloat16
+                    out_dtype = y.dtype                     # what add_layer_norm_fn hands a block's in_proj
                 else:
                     norm, scale, out_dtype = self.norm_f, None, self.norm_f.weight.dtype
                 if out_proj_add_ln_ok(y, prev.out_proj.weight, prev.d_model):

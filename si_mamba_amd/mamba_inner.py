@@ -41,8 +41,10 @@ def _xw(X, W):
 
 
 def _sum_bmm(X, Y):
-    """sum_b X[b] (M, K) @ Y[b] (K, N) -> (M, N): a weight gradient."""
-    return torch.bmm(X, Y).sum(0)
+    """sum_b X[b] (M, K) @ Y[b] (K, N) -> (M, N): a weight gradient.  The batch sum accumulates and RETURNS fp32 (for
+    16-bit operands too: the parameters it goes to are fp32 under autocast, so the cast kernel that would follow -- one
+    launch per weight, layer and step -- never runs, and the sum of 64 partials is not rounded to bf16 first)."""
+    return torch.bmm(X, Y).sum(0, dtype=torch.float32)
 
 
 class InProjFn(torch.autograd.Function):
