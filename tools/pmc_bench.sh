@@ -11,7 +11,7 @@ mkdir -p $OUT
 i=0
 for ctrs in "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE"; do
   i=$((i+1))
-  timeout -k 10 400 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d $OUT/p$i -- python3 bench.py --dtype $DT --steps 2 --warmup 1 --no-cpu-baseline --no-headline > $OUT/p$i.log 2>&1
+  timeout -k 10 400 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d $OUT/p$i -- python3 bench.py --dtype $DT --steps 2 --warmup 1 --no-cpu-baseline --no-headline --no-bf16-step > $OUT/p$i.log 2>&1
   rc=$?; echo "[pmc pass $i] rc=$rc"
   if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then exit 1; fi
 done
