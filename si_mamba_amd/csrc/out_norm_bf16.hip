@@ -181,8 +181,8 @@ __global__ __launch_bounds__(kOnThreads, 2) void out_proj_add_ln_kernel(OnArgs p
   load_y(yb, 1);
   store_y(ya, 0);
 #ifndef ON_NK
-#define ON_NK nk
-#endif
+#define ON_NK nk                            // timing-only A/B builds (tools/build_alt.sh): -DON_NK=2 = 2 K-steps, i.e. the
+#endif                                   // epilogue's share; -DON_ROWS=1 below = the main loop's (profiles/r03c_out_norm.txt)
   for (int ks = 0; ks < ON_NK; ks += 2) {
     __syncthreads();
     store_y(yb, 1);
