@@ -365,6 +365,18 @@ def main():
                      "dtype": "bf16 autocast (parameters, optimizer, reductions, scan state fp32)",
                      "finite_loss": bool(torch.isfinite(loss16).item()),
                      "note": "measured after the timed fp32 region on the same model and data; not the headline"}
+        if not args.no_kernel_timing:
+            # two more bf16 steps with every HIP launch event-bracketed (untimed), and which routes the mixer took:
+            # delta formed inside the scans (scan_dt_fwd) and out_proj + add + LayerNorm as one kernel (out_proj_add_ln)
+            _lib.counters.clear()
+            _lib.enable_kernel_timing(True)
+            for _ in range(2):
+                step(amp16)
+            sync()
+            bf16_step["kernels"] = {k: {"launches": v[0], "mean_ms": round(v[1], 4)}
+                                    for k, v in _lib.kernel_times().items()}
+            bf16_step["routes"] = dict(_lib.counters)
+            _lib.enable_kernel_timing(False)
 
     if rank == 0:
         L = 2 * cfg.k_top_eigenvectors * args.groups

@@ -10,7 +10,7 @@ from si_mamba_amd.add_norm import add_layer_norm_fn
 from si_mamba_amd.out_norm import out_proj_add_ln_fn
 
 dev = torch.device("cuda:0")
-B, C, L = int(os.environ.get("B", 64)), 384, 1024
+B, C, L = int(os.environ.get("B", 64)), 384, int(os.environ.get("L", 1024))
 K = 2 * C
 g = torch.Generator(device="cuda").manual_seed(0)
 y = torch.randn(B, K, L, device=dev, generator=g).bfloat16()
@@ -45,5 +45,5 @@ with torch.no_grad():
         torch.cuda.synchronize()
         us = a.elapsed_time(e) / 20 * 1e3
         hbm = (B * K * L * 2 + C * K * 2 + 2 * B * L * C * 4 + B * L * C * 2) / 1e6
-        print(f"{name:32s} {us:7.1f} us   ({hbm:.0f} MB algorithmic for the fused op -> {hbm / us * 1e-3 * 1e3:.0f} GB/s; "
+        print(f"B={B} L={L} {name:32s} {us:7.1f} us   ({hbm:.0f} MB algorithmic for the fused op -> {hbm / us * 1e-3 * 1e3:.0f} GB/s; "
               f"{2 * B * L * C * K / us * 1e-6:.0f} TF/s)", flush=True)
