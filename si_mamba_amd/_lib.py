@@ -67,6 +67,7 @@ SIGNATURES = {
                                            c_int, c_int, _P]),
     "simamba_out_proj_add_ln_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float,
                                             c_int, _P]),
+    "simamba_in_proj_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "simamba_bn_relu_grid": (c_int, [_LL]),
     "simamba_bn_relu_fwd": (c_int, [_P, _P, c_int, _P, _P, _P, _P, c_float, c_float, c_int, _P, _P, _P, _P, _LL, c_int,
                                     _LL, c_int, _P]),
@@ -271,6 +272,7 @@ def fuse_dt_enabled(dtype):
 
 
 _fuse_out_norm = [True]
+_hand_in_proj = [None]   # None: the measured default (in_proj_hand_enabled); True / False: forced
 
 
 class fuse_out_norm:
@@ -291,6 +293,30 @@ class fuse_out_norm:
 
 def fuse_out_norm_enabled():
     return _fuse_out_norm[0]
+
+
+class hand_in_proj:
+    """Context manager for benchmarks and parity tests: in_proj through the hand-written bf16 kernel
+    (simamba_in_proj_fwd) wherever its shapes apply (True) or through the library GEMM (False)."""
+
+    def __init__(self, on):
+        self.v, self.prev = (None if on is None else bool(on)), None
+
+    def __enter__(self):
+        self.prev, _hand_in_proj[0] = _hand_in_proj[0], self.v
+        return self
+
+    def __exit__(self, *exc):
+        _hand_in_proj[0] = self.prev
+        return False
+
+
+def in_proj_hand_enabled(workgroups):
+    """Default: only grids that fill the chip (a workgroup owns 256 tokens of one sample and is alone on its CU)."""
+    return (workgroups >= IN_PROJ_MIN_WORKGROUPS) if _hand_in_proj[0] is None else _hand_in_proj[0]
+
+
+IN_PROJ_MIN_WORKGROUPS = 192
 
 
 def scan_plan(batch, dim, seqlen, dstate, dtype, aligned, device, need_grad):

@@ -57,7 +57,21 @@ class InProjFn(torch.autograd.Function):
             io = torch.get_autocast_dtype("cuda")
             hidden = hidden.to(io)
         wc = _w(weight, io)
-        xz = _wx(wc, hidden.transpose(1, 2))
+        xz = None
+        if (io == torch.bfloat16 and bias is None and hidden.is_cuda and hidden.dim() == 3 and hidden.is_contiguous()
+                and in_proj_hand_ok(hidden, wc)):
+            # the hand-written bf16 MFMA kernel (csrc/in_proj_bf16.hip): same product, same single rounding to bf16
+            lib = _lib.load()
+            Bsz, L, C = hidden.shape
+            wcc = wc.contiguous()
+            xz = torch.empty(Bsz, wc.shape[0], L, device=hidden.device, dtype=io)
+            with torch.cuda.device(hidden.device), _lib.timed("in_proj_fwd", hidden.device):
+                rc = lib.simamba_in_proj_fwd(hidden.data_ptr(), wcc.data_ptr(), xz.data_ptr(), Bsz, L, C, wc.shape[0],
+                                             _lib.stream_ptr(hidden.device))
+            _lib.check(rc, "simamba_in_proj_fwd")
+            _lib.count("in_proj_hand")
+        if xz is None:
+            xz = _wx(wc, hidden.transpose(1, 2))
         if bias is not None:
             xz = xz + _w(bias, io)[None, :, None]
         ctx.save_for_backward(hidden, weight)
@@ -74,6 +88,13 @@ class InProjFn(torch.autograd.Function):
         dw = _sum_bmm(dxz, hidden).to(weight.dtype) if ctx.needs_input_grad[1] else None     # (2D, d)
         db = dxz.sum((0, 2)).to(weight.dtype) if ctx.has_bias else None
         return dh, dw, db
+
+
+def in_proj_hand_ok(hidden, wc):
+    """Shapes the hand-written in_proj kernel takes (include/simamba.h) and grids that fill the chip."""
+    Bsz, L, C = hidden.shape
+    return (C % 64 == 0 and C <= 384 and wc.shape[0] % 32 == 0 and L % 8 == 0 and hidden.data_ptr() % 16 == 0
+            and _lib.in_proj_hand_enabled(Bsz * ((L + 255) // 256)))
 
 
 def in_proj_fn(hidden, weight, bias=None):
