@@ -57,21 +57,7 @@ class InProjFn(torch.autograd.Function):
             io = torch.get_autocast_dtype("cuda")
             hidden = hidden.to(io)
         wc = _w(weight, io)
-        xz = None
-        if (io == torch.bfloat16 and bias is None and hidden.is_cuda and hidden.dim() == 3 and hidden.is_contiguous()
-                and in_proj_hand_ok(hidden, wc)):
-            # the hand-written bf16 MFMA kernel (csrc/in_proj_bf16.hip): same product, same single rounding to bf16
-            lib = _lib.load()
-            Bsz, L, C = hidden.shape
-            wcc = wc.contiguous()
-            xz = torch.empty(Bsz, wc.shape[0], L, device=hidden.device, dtype=io)
-            with torch.cuda.device(hidden.device), _lib.timed("in_proj_fwd", hidden.device):
-                rc = lib.simamba_in_proj_fwd(hidden.data_ptr(), wcc.data_ptr(), xz.data_ptr(), Bsz, L, C, wc.shape[0],
-                                             _lib.stream_ptr(hidden.device))
-            _lib.check(rc, "simamba_in_proj_fwd")
-            _lib.count("in_proj_hand")
-        if xz is None:
-            xz = _wx(wc, hidden.transpose(1, 2))
+        xz = tokens_times_weight(hidden, wc) if bias is None else _wx(wc, hidden.transpose(1, 2))
         if bias is not None:
             xz = xz + _w(bias, io)[None, :, None]
         ctx.save_for_backward(hidden, weight)
@@ -88,6 +74,25 @@ class InProjFn(torch.autograd.Function):
         dw = _sum_bmm(dxz, hidden).to(weight.dtype) if ctx.needs_input_grad[1] else None     # (2D, d)
         db = dxz.sum((0, 2)).to(weight.dtype) if ctx.has_bias else None
         return dh, dw, db
+
+
+def tokens_times_weight(x, w):
+    """out[b, j, t] = sum_c w[j, c] x[b, t, c]: token-major (B, L, C) activations against a row-major (M, C) weight, result
+    (B, M, L) with L contiguous -- the shape of in_proj's forward and of out_proj's input gradient.  bf16 operands whose
+    grid fills the chip go through the hand-written kernel (csrc/in_proj_bf16.hip), anything else through the library."""
+    if (x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and x.is_cuda and x.dim() == 3 and x.is_contiguous()
+            and in_proj_hand_ok(x, w)):
+        lib = _lib.load()
+        Bsz, L, C = x.shape
+        wcc = w.contiguous()
+        out = torch.empty(Bsz, w.shape[0], L, device=x.device, dtype=x.dtype)
+        with torch.cuda.device(x.device), _lib.timed("in_proj_fwd", x.device):
+            rc = lib.simamba_in_proj_fwd(x.data_ptr(), wcc.data_ptr(), out.data_ptr(), Bsz, L, C, w.shape[0],
+                                         _lib.stream_ptr(x.device))
+        _lib.check(rc, "simamba_in_proj_fwd")
+        _lib.count("in_proj_hand")
+        return out
+    return _wx(w, x.transpose(1, 2))
 
 
 def in_proj_hand_ok(hidden, wc):
@@ -264,7 +269,7 @@ class MambaInnerFn(torch.autograd.Function):
             # out_proj
             d_out_w = _sum_bmm(dout.transpose(1, 2), y.transpose(1, 2))               # (d, D)
             d_out_b = dout.sum((0, 1)) if ctx.has_out_bias else None
-            dy = _wx(ow_c.t(), dout.transpose(1, 2))                                  # (B, D, L)
+            dy = tokens_times_weight(dout, ow_c.t())                                  # (B, D, L)
 
         # selective scan
         dxz = torch.empty_like(xz)

@@ -10,7 +10,8 @@ What the reference computes across a block boundary under autocast -- the mixer'
     normed   = LayerNorm(residual)
 
 One kernel forward: the out_proj result never goes to memory.  Backward: the LayerNorm / add backward kernel of
-add_norm.py, then the two out_proj gradient products through the library.  bf16 operands only (the autocast
+add_norm.py, then out_proj's input gradient through the hand-written token-times-weight kernel (csrc/in_proj_bf16.hip;
+the library GEMM where its grid would not fill the chip) and its weight gradient through the library.  bf16 operands only (the autocast
 configurations); MixerModel.forward takes this route when it applies and the reference's op-by-op route otherwise.
 """
 from __future__ import annotations
@@ -18,7 +19,7 @@ from __future__ import annotations
 import torch
 
 from . import _lib
-from .mamba_inner import _sum_bmm, _wx
+from .mamba_inner import _sum_bmm, tokens_times_weight
 
 
 def out_proj_add_ln_ok(y, out_w, d_model):
@@ -76,7 +77,7 @@ class OutProjAddLnFn(torch.autograd.Function):
                                                 _lib.stream_ptr(dev))
         _lib.check(rc, "simamba_add_layer_norm_bwd")
         dwb = part.sum(0)
-        dy = _wx(wc.t(), dhid.transpose(1, 2))                                    # (B, D, L)
+        dy = tokens_times_weight(dhid, wc.t())                                    # (B, D, L)
         d_out_w = _sum_bmm(dhid.transpose(1, 2), y.transpose(1, 2))               # (C, D)
         return (dy, d_out_w.to(owdtype), None if not has_res else dres.to(res_dtype), dwb[0].to(lwdtype),
                 dwb[1].to(lwdtype) if has_bias else None, None, None, None)
