@@ -52,6 +52,11 @@ __device__ __forceinline__ void ip_static_for(F&& f) {
 // A 16-byte LDS read the compiler can neither sink next to its use nor count: issued here, waited for by ip_lds_wait.
 // (Left to itself hipcc moved every A-fragment read directly in front of its MFMAs and waited lgkmcnt(0) each time --
 // one LDS latency per k step, 2.5 us per channel block at one wave per SIMD.)
+// Contract: the destination may only be READ through ip_lds_wait (which hands the compiler a new value): to hipcc the
+// register is defined the moment this statement issues.  A copy of it made before the wait -- a live-range split or a
+// spill into an AGPR under register pressure -- would copy stale contents; the current builds make none (checked in the
+// .s: every ds_read_b128 destination is next touched by the s_waitcnt statement or the MFMA behind it), and
+// tests/test_gpu_in_proj.py compares every output element on every build.
 template <int OFF>
 __device__ __forceinline__ void ip_lds_read16(ip_u4& dst, unsigned addr) {
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
