@@ -16,7 +16,7 @@
  *                                    upstream's mamba_inner_fn).
  *   simamba_add_layer_norm_fwd/bwd   the Add -> LayerNorm of models/block.py:56-60 (torch ops there).
  *   simamba_out_proj_add_ln_fwd      out_proj of the mixer + that Add -> LayerNorm, one kernel (bf16).
- *   simamba_in_proj_fwd              in_proj of the same mixer (a cuBLAS GEMM upstream), bf16.
+ *   simamba_in_proj_fwd              in_proj of the same mixer (a cuBLAS GEMM upstream), fp32 and bf16.
  *   simamba_selective_scan_dt_fwd/bwd  the scan with delta formed in the kernel (same call site, bf16 path).
  *   simamba_knn_graph                models/point_mamba.py:620-661 and :664-715
  *                                    (create_graph_from_centers / ..._feature_space_...).
@@ -275,14 +275,17 @@ int simamba_out_proj_add_ln_fwd(const void* y, const void* w, const float* resid
                                 float* rstd, int batch, int K, int L, int C, float eps, int out_dtype, void* stream);
 
 /*
- * in_proj of the mixer on the matrix cores, bf16 (the first product of upstream's Mamba.forward, reached from
- * models/block.py:72):  xz[b, j, t] = sum_c w[j, c] * x[b, t, c].
- *   x : (batch, L, C) bf16, token-major (the LayerNorm output) ; w : (M, C) bf16 ; xz : (batch, M, L) bf16, L contiguous
- *   (the layout the conv / scan kernels stream).  fp32 accumulation, one rounding to bf16.
- * C % 64 == 0, C <= 384, M % 32 == 0, L % 8 == 0, 16-byte aligned pointers.  A workgroup owns 256 tokens of one sample:
- * grids of fewer than ~200 workgroups (batch * ceil(L / 256)) leave CUs idle and are better served by the library GEMM.
+ * in_proj of the mixer on the matrix cores (the first product of upstream's Mamba.forward, reached from
+ * models/block.py:72):  xz[b, j, t] = sum_c w[j, c] * x[b, t, c].  Also the shape of out_proj's input gradient.
+ *   x : (batch, L, C) io_dtype, token-major (the LayerNorm output) ; w : (M, C) io_dtype ; xz : (batch, M, L) io_dtype,
+ *   L contiguous (the layout the conv / scan kernels stream).  fp32: exact fp32 MFMA (an fmaf chain); bf16: fp32
+ *   accumulation, one rounding to bf16.
+ * C % 64 == 0, C <= 384, M % 32 == 0, L % 8 == 0 (fp32: L % 4 == 0), 16-byte aligned pointers.  A workgroup owns 256
+ * (fp32: 128) tokens of one sample: grids of fewer than ~200 workgroups leave CUs idle and are better served by the
+ * library GEMM.
  */
-int simamba_in_proj_fwd(const void* x, const void* w, void* xz, int batch, int L, int C, int M, void* stream);
+int simamba_in_proj_fwd(const void* x, const void* w, void* xz, int batch, int L, int C, int M, int io_dtype,
+                        void* stream);
 
 /*
  * Patch-encoder streaming ops (reference models/point_mamba.py:46-73, Encoder: Conv1d - BatchNorm1d - ReLU -

@@ -67,7 +67,7 @@ SIGNATURES = {
                                            c_int, c_int, _P]),
     "simamba_out_proj_add_ln_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float,
                                             c_int, _P]),
-    "simamba_in_proj_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "simamba_in_proj_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "simamba_bn_relu_grid": (c_int, [_LL]),
     "simamba_bn_relu_fwd": (c_int, [_P, _P, c_int, _P, _P, _P, _P, c_float, c_float, c_int, _P, _P, _P, _P, _LL, c_int,
                                     _LL, c_int, _P]),
@@ -311,9 +311,13 @@ class hand_in_proj:
         return False
 
 
-def in_proj_hand_enabled(workgroups):
-    """Default: only grids that fill the chip (a workgroup owns 256 tokens of one sample and is alone on its CU)."""
-    return (workgroups >= IN_PROJ_MIN_WORKGROUPS) if _hand_in_proj[0] is None else _hand_in_proj[0]
+def in_proj_hand_enabled(workgroups, dtype=None):
+    """Default: bf16 only (102 us against 116 us for the library GEMM; the fp32 form measured 650 against 535 us and stays an
+    explicit variant), and only grids that fill the chip (a workgroup owns 256 tokens of one sample, alone on its CU)."""
+    import torch
+    if _hand_in_proj[0] is not None:
+        return _hand_in_proj[0]
+    return dtype != torch.float32 and workgroups >= IN_PROJ_MIN_WORKGROUPS
 
 
 IN_PROJ_MIN_WORKGROUPS = 192

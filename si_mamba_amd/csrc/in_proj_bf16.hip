@@ -214,7 +214,6 @@ __global__ __launch_bounds__(kIpThreads, kIpSets == 1 ? 2 : 1) void in_proj_bf16
     constexpr bool kSpread = NS >= kLd + kNO + 6;            // room to hand the side work out one piece per step
     const bool so = blk > 1;
     ip_u4 o[kNO];
-    if (so) out_read(o, par_tag);                            // block blk - 2, parked in sO[buf] during block blk - 1
 #pragma unroll
     for (int u = 0; u < kIpSets; ++u)
 #pragma unroll
@@ -224,13 +223,7 @@ __global__ __launch_bounds__(kIpThreads, kIpSets == 1 ? 2 : 1) void in_proj_bf16
       constexpr int S = decltype(sc)::value;
       ip_lds_read16<buf * kWBuf + 32 * S>(a[S], aaddr);
     });
-    if (!kSpread && so) {
-#pragma unroll
-      for (int i = 0; i < kNO; ++i) {
-        ip_lds_wait<(kAhead < NS ? kAhead : NS)>(o[i]);
-        out_store(o[i], blk - 2, i);
-      }
-    }
+    if (!kSpread && so) store_out(blk - 2, par_tag);         // block blk - 2, parked in sO[buf] during block blk - 1
     ip_static_for<0, NS>([&](auto sc) {
       constexpr int S = decltype(sc)::value;
       // reads S + 1 .. min(S + kAhead, NS) - 1 may still be in flight (plus whatever the compiler has issued since: the
@@ -262,6 +255,11 @@ __global__ __launch_bounds__(kIpThreads, kIpSets == 1 ? 2 : 1) void in_proj_bf16
         // for all but the youngest few before it touches the W registers above -- with this block's stores already in
         // flight that wait sat on their retirement (~1-2 us under a chip-wide write stream), every block.  Issued here
         // they are a whole block old when the next wait comes.
+        // (read two steps before the stores: the destination of an asm read must not live long enough to be moved
+        // aside before its data has landed -- the fp32 form did exactly that with reads held from the top of the block)
+        if constexpr (S == NS - 3) {
+          if (so) out_read(o, par_tag);                      // block blk - 2, parked in sO[buf] during block blk - 1
+        }
         if constexpr (S == NS - 1) {
           if (so) {
 #pragma unroll
@@ -319,19 +317,25 @@ static void ip_launch(const IpArgs& a, hipStream_t s) {
   hipLaunchKernelGGL((in_proj_bf16_kernel<NS>), dim3(static_cast<unsigned>(a.batch) * tps), dim3(kIpThreads), 0, s, a);
 }
 
+int in_proj_f32_dispatch(const void* x, const void* w, void* xz, int batch, int L, int C, int M, hipStream_t s);   // in_proj_f32.hip
+
 }  // namespace simamba
 
 using namespace simamba;
 
-extern "C" int simamba_in_proj_fwd(const void* x, const void* w, void* xz, int batch, int L, int C, int M, void* stream) {
+extern "C" int simamba_in_proj_fwd(const void* x, const void* w, void* xz, int batch, int L, int C, int M, int io_dtype,
+                                   void* stream) {
+  if (io_dtype != SIMAMBA_F32 && io_dtype != SIMAMBA_BF16) return SIMAMBA_E_DTYPE;
   if (batch < 0 || L < 0 || C <= 0 || M <= 0) return SIMAMBA_E_SHAPE;
-  // whole 64-deep groups of k steps (one 16-byte W load per thread and 64 k), 32-channel blocks, 8-token store chunks
-  if (C % 64 || C > 384 || M % kIpCb || L % 8) return SIMAMBA_E_SHAPE;
+  // whole 64-deep groups of k steps (one 16-byte W load per thread and 64 k), 32-channel blocks, 16-byte store chunks
+  if (C % 64 || C > 384 || M % kIpCb || L % (io_dtype == SIMAMBA_F32 ? 4 : 8)) return SIMAMBA_E_SHAPE;
   if (batch == 0 || L == 0) return SIMAMBA_OK;
   if (!x || !w || !xz) return SIMAMBA_E_NULLPTR;
   if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(xz)) & 15u)
     return SIMAMBA_E_ALIGN;
-  if (static_cast<long long>(batch) * ((L + kIpTok - 1) / kIpTok) > 0x7fffffffLL) return SIMAMBA_E_SHAPE;
+  if (static_cast<long long>(batch) * ((L + 127) / 128) > 0x7fffffffLL) return SIMAMBA_E_SHAPE;
+  if (io_dtype == SIMAMBA_F32)
+    return in_proj_f32_dispatch(x, w, xz, batch, L, C, M, static_cast<hipStream_t>(stream));
   IpArgs a{static_cast<const uint16_t*>(x), static_cast<const uint16_t*>(w), static_cast<uint16_t*>(xz), batch, L, C, M};
   hipStream_t s = static_cast<hipStream_t>(stream);
   switch (C / 64) {

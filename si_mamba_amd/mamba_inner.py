@@ -79,16 +79,17 @@ class InProjFn(torch.autograd.Function):
 def tokens_times_weight(x, w):
     """out[b, j, t] = sum_c w[j, c] x[b, t, c]: token-major (B, L, C) activations against a row-major (M, C) weight, result
     (B, M, L) with L contiguous -- the shape of in_proj's forward and of out_proj's input gradient.  bf16 operands whose
-    grid fills the chip go through the hand-written kernel (csrc/in_proj_bf16.hip), anything else through the library."""
-    if (x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and x.is_cuda and x.dim() == 3 and x.is_contiguous()
-            and in_proj_hand_ok(x, w)):
+    grid fills the chip go through the hand-written kernels (csrc/in_proj_bf16.hip, csrc/in_proj_f32.hip), anything else
+    through the library."""
+    if (x.dtype in (torch.bfloat16, torch.float32) and w.dtype == x.dtype and x.is_cuda and x.dim() == 3
+            and x.is_contiguous() and in_proj_hand_ok(x, w)):
         lib = _lib.load()
         Bsz, L, C = x.shape
         wcc = w.contiguous()
         out = torch.empty(Bsz, w.shape[0], L, device=x.device, dtype=x.dtype)
         with torch.cuda.device(x.device), _lib.timed("in_proj_fwd", x.device):
             rc = lib.simamba_in_proj_fwd(x.data_ptr(), wcc.data_ptr(), out.data_ptr(), Bsz, L, C, w.shape[0],
-                                         _lib.stream_ptr(x.device))
+                                         _lib.dtype_code(x.dtype), _lib.stream_ptr(x.device))
         _lib.check(rc, "simamba_in_proj_fwd")
         _lib.count("in_proj_hand")
         return out
@@ -98,8 +99,9 @@ def tokens_times_weight(x, w):
 def in_proj_hand_ok(hidden, wc):
     """Shapes the hand-written in_proj kernel takes (include/simamba.h) and grids that fill the chip."""
     Bsz, L, C = hidden.shape
+    tile = 128 if hidden.dtype == torch.float32 else 256       # tokens per workgroup
     return (C % 64 == 0 and C <= 384 and wc.shape[0] % 32 == 0 and L % 8 == 0 and hidden.data_ptr() % 16 == 0
-            and _lib.in_proj_hand_enabled(Bsz * ((L + 255) // 256)))
+            and _lib.in_proj_hand_enabled(Bsz * ((L + tile - 1) // tile), hidden.dtype))
 
 
 def in_proj_fn(hidden, weight, bias=None):

@@ -12,13 +12,14 @@ def nerr(got, want):
     return ((got - want).abs().max() / max(1.0, want.abs().max().item())).item()
 
 
-def _call(x, w, device):
+def _call(x, w, device, dtype=torch.bfloat16):
     from si_mamba_amd import _lib
     lib = _lib.load()
     B, L, C = x.shape
     M = w.shape[0]
-    xz = torch.full((B, M, L), float("nan"), device=device, dtype=torch.bfloat16)
-    rc = lib.simamba_in_proj_fwd(x.data_ptr(), w.data_ptr(), xz.data_ptr(), B, L, C, M, _lib.stream_ptr(x.device))
+    xz = torch.full((B, M, L), float("nan"), device=device, dtype=dtype)
+    rc = lib.simamba_in_proj_fwd(x.data_ptr(), w.data_ptr(), xz.data_ptr(), B, L, C, M, _lib.dtype_code(x.dtype),
+                                 _lib.stream_ptr(x.device))
     return rc, xz
 
 
@@ -38,17 +39,55 @@ def test_in_proj_kernel_matches_float64_product(B, L, C, M, device):
     assert (err <= 2.0 ** -8 * want.abs() + 1e-3).all()
 
 
+@pytest.mark.parametrize("B,L,C,M", [(2, 128, 384, 1536), (1, 1024, 384, 768), (3, 72, 128, 512), (2, 260, 64, 64),
+                                     (1, 4, 192, 96), (2, 132, 256, 1024), (1, 512, 320, 640)])
+def test_in_proj_f32_kernel_matches_float64_product(B, L, C, M, device):
+    """The fp32 form (csrc/in_proj_f32.hip, exact-fp32 MFMA): every K depth it instantiates, ragged 128-token tiles;
+    fp32 accumulation error only (north-star 1e-3; observed ~1e-6)."""
+    g = torch.Generator().manual_seed(B * 1000 + L + 7)
+    x = torch.randn(B, L, C, generator=g).to(device)
+    w = (torch.randn(M, C, generator=g) * C ** -0.5).to(device)
+    rc, xz = _call(x, w, device, torch.float32)
+    assert rc == 0
+    want = torch.einsum("jc,blc->bjl", w.double().cpu(), x.double().cpu())
+    assert torch.isfinite(xz).all()
+    assert nerr(xz, want) < 2e-6 * max(1.0, C ** 0.5 / 8)
+
+
 def test_in_proj_kernel_refuses_what_it_does_not_take(device):
     from si_mamba_amd import _lib
     x = torch.zeros(1, 16, 100, device=device, dtype=torch.bfloat16)
     w = torch.zeros(64, 100, device=device, dtype=torch.bfloat16)
     rc, _ = _call(x, w, device)                                     # C % 64
-    assert rc == _lib.load().simamba_in_proj_fwd(None, None, None, 1, 16, 100, 64, None) != 0
+    assert rc == _lib.load().simamba_in_proj_fwd(None, None, None, 1, 16, 100, 64, _lib.BF16, None) != 0
     x = torch.zeros(1, 12, 64, device=device, dtype=torch.bfloat16)   # L % 8
     w = torch.zeros(64, 64, device=device, dtype=torch.bfloat16)
     assert _call(x, w, device)[0] != 0
     x = torch.zeros(0, 16, 64, device=device, dtype=torch.bfloat16)   # empty batch: nothing to do
     assert _call(x, w, device)[0] == 0
+
+
+@pytest.mark.parametrize("B,L", [(4, 256), (2, 1024)])
+def test_in_proj_fn_hand_route_matches_library_route_fp32(B, L, device):
+    """fp32 (no autocast): hand kernel against the library GEMM at fp32 accumulation noise, backward identical."""
+    from si_mamba_amd import _lib
+    from si_mamba_amd.mamba_inner import in_proj_fn
+    g = torch.Generator().manual_seed(6)
+    h = torch.randn(B, L, 384, generator=g).to(device)
+    w = (torch.randn(1536, 384, generator=g) * 384 ** -0.5).to(device)
+    dout = torch.randn(B, 1536, L, generator=g).to(device)
+    res = {}
+    for hand in (True, False):
+        hh, ww = h.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        _lib.counters.pop("in_proj_hand", None)
+        with _lib.hand_in_proj(hand):
+            xz = in_proj_fn(hh, ww)
+        assert _lib.counters.get("in_proj_hand", 0) == (1 if hand else 0)
+        assert xz.dtype == torch.float32 and xz.shape == (B, 1536, L)
+        (xz * dout).sum().backward()
+        res[hand] = (xz.detach(), hh.grad, ww.grad)
+    assert nerr(res[True][0], res[False][0]) < 1e-5
+    assert nerr(res[True][1], res[False][1]) < 1e-6 and nerr(res[True][2], res[False][2]) < 1e-6
 
 
 @pytest.mark.parametrize("B,L", [(4, 256), (2, 1024)])
