@@ -32,6 +32,8 @@ typedef __bf16 ip_bf16x8 __attribute__((ext_vector_type(8)));
 // spaces, and an array of them that lives across loop iterations then stays in scratch memory instead of registers
 typedef unsigned ip_u4 __attribute__((ext_vector_type(4)));
 
+// Timing-only A/B switches (tools/build_alt.sh; the elimination numbers of DESIGN 4.10): -DIP_NOSTORE drops the global stores,
+// -DIP_NOWLOAD reloads W block 0 for every block, -DIP_NOMFMA issues one MFMA per block.  Outputs are wrong by construction.
 constexpr int kIpThreads = 256;
 constexpr int kIpCb = 32;            // output channels per block
 #ifndef SIMAMBA_INPROJ_SETS
