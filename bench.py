@@ -18,6 +18,7 @@ bf16 I/O), "kernels" (mean ms per launch of the two scan kernels, event-brackete
 from __future__ import annotations
 
 import argparse
+import gc
 import json
 import os
 import sys
@@ -320,6 +321,7 @@ def main():
     # step costs 0.5 ms (fp32) to 7 ms (bf16, CPU-bound then) of the step it measures
     _lib.enable_kernel_timing(not args.no_kernel_timing, only=("scan_fwd", "scan_bwd"))
     _lib._scan_variant[0] = args.scan_variant
+    gc.collect()        # a full collection of the interpreter (~80 ms with this many live tensors) now, not inside the region
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -350,6 +352,7 @@ def main():
         amp16 = torch.autocast("cuda", dtype=torch.bfloat16)
         for _ in range(3):
             step(amp16)
+        gc.collect()
         sync()
         t1 = time.perf_counter()
         for _ in range(10):
