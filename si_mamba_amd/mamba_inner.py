@@ -11,8 +11,10 @@ ops it never copies an activation-sized tensor:
   * every GEMM is issued in the orientation that yields an L-contiguous ``(B, *, L)`` result, so no
     transposition kernel runs.
 
-in_proj, out_proj and every backward product are library GEMMs (hipBLASLt / rocBLAS through torch.bmm); the skinny
-x_proj -> dt_proj pair of the fp32 forward is one hand-written MFMA kernel (csrc/xdt_proj.hip).
+Hand-written MFMA kernels: conv1d + SiLU -> x_proj (-> dt_proj) (csrc/xdt_proj.hip, xdt_proj_bf16.hip), and under bf16
+compute in_proj / out_proj's input gradient (csrc/in_proj_bf16.hip, via tokens_times_weight) and out_proj fused with the
+next block's add + LayerNorm (out_norm.py).  The fp32 in_proj / out_proj and the remaining backward products are library
+GEMMs (hipBLASLt / rocBLAS through torch.bmm).
 """
 from __future__ import annotations
 
